@@ -1,0 +1,198 @@
+// Shared device/host helpers for libfluidnet_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/fluidnet_hip.h"
+
+typedef uint16_t bf16_t;  // raw bf16 bits
+
+// ---------------------------------------------------------------- bf16 <-> f32
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    // round-to-nearest-even; NaN stays NaN (quiet)
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+
+// 8-channel vector load/store for P-tensors (C % 8 == 0, channel offsets % 8 == 0)
+template <typename T>
+struct Vec8;
+template <>
+struct Vec8<float> {
+    float v[8];
+    __device__ __forceinline__ void load(const float* p) {
+        const float4 a = *reinterpret_cast<const float4*>(p);
+        const float4 b = *reinterpret_cast<const float4*>(p + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    }
+    __device__ __forceinline__ void store(float* p) const {
+        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+};
+template <>
+struct Vec8<bf16_t> {
+    float v[8];
+    __device__ __forceinline__ void load(const bf16_t* p) {
+        const uint4 a = *reinterpret_cast<const uint4*>(p);
+        const uint32_t w[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            v[2 * k] = __uint_as_float(w[k] << 16);
+            v[2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u);
+        }
+    }
+    __device__ __forceinline__ void store(bf16_t* p) const {
+        uint32_t w[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) w[k] = (uint32_t)f2bf(v[2 * k]) | ((uint32_t)f2bf(v[2 * k + 1]) << 16);
+        *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+};
+
+template <typename T>
+__device__ __forceinline__ float ld1(const T* p);
+template <>
+__device__ __forceinline__ float ld1<float>(const float* p) { return *p; }
+template <>
+__device__ __forceinline__ float ld1<bf16_t>(const bf16_t* p) { return bf2f(*p); }
+template <typename T>
+__device__ __forceinline__ void st1(T* p, float v);
+template <>
+__device__ __forceinline__ void st1<float>(float* p, float v) { *p = v; }
+template <>
+__device__ __forceinline__ void st1<bf16_t>(bf16_t* p, float v) { *p = f2bf(v); }
+
+// ---------------------------------------------------------------- padding-ring index maps
+// Source interior index for padded-domain index i in [-1, n]; -1 means "constant zero".
+__host__ __device__ __forceinline__ int pad_src(int i, int n, int pm) {
+    if (i >= 0 && i < n) return i;
+    switch (pm) {
+        case FNET_PAD_REPLICATE: return i < 0 ? 0 : n - 1;
+        case FNET_PAD_REFLECT: return i < 0 ? 1 : n - 2;
+        case FNET_PAD_CIRCULAR: return i < 0 ? n - 1 : 0;
+        default: return -1;
+    }
+}
+// Padded coordinates (0..n+1) whose value is a copy of interior index i (the adjoint "fold" set).
+__host__ __device__ __forceinline__ int fold_list(int i, int n, int pm, int out[3]) {
+    int k = 0;
+    out[k++] = i + 1;
+    if (pm != FNET_PAD_ZEROS) {
+        if (pad_src(-1, n, pm) == i) out[k++] = 0;
+        if (pad_src(n, n, pm) == i) out[k++] = n + 1;
+    }
+    return k;
+}
+
+// ---------------------------------------------------------------- activations (ml/models/unet.py:31-39)
+__device__ __forceinline__ float act_fwd(float u, int act) {
+    switch (act) {
+        case FNET_ACT_RELU: return u > 0.f ? u : 0.f;
+        case FNET_ACT_LEAKY: return u > 0.f ? u : 0.1f * u;
+        case FNET_ACT_GELU: return 0.5f * u * (1.f + erff(u * 0.70710678118654752f));
+        case FNET_ACT_SILU: return u / (1.f + __expf(-u));
+        default: return u;
+    }
+}
+__device__ __forceinline__ float act_bwd(float u, int act) {
+    switch (act) {
+        case FNET_ACT_RELU: return u > 0.f ? 1.f : 0.f;
+        case FNET_ACT_LEAKY: return u > 0.f ? 1.f : 0.1f;
+        case FNET_ACT_GELU:
+            return 0.5f * (1.f + erff(u * 0.70710678118654752f)) + u * 0.3989422804014327f * __expf(-0.5f * u * u);
+        case FNET_ACT_SILU: {
+            const float s = 1.f / (1.f + __expf(-u));
+            return s * (1.f + u * (1.f - s));
+        }
+        default: return 1.f;
+    }
+}
+
+// ---------------------------------------------------------------- Dropout2d channel mask
+// Counter-based: keep(n,c) depends only on (seed, site id, n, c) so that forward and backward agree and the
+// host can reproduce the mask (fluidnet_amd/engine/dropout.py).  Returns the multiplier 0 or 1/(1-p).
+__host__ __device__ __forceinline__ uint32_t fnet_mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+    return x;
+}
+__host__ __device__ __forceinline__ float drop_scale(uint32_t seed, uint32_t site, uint32_t n, uint32_t c, float p) {
+    if (p <= 0.f) return 1.f;
+    uint32_t h = fnet_mix32(seed ^ fnet_mix32(site * 0x9E3779B1u + 0x7F4A7C15u));
+    h = fnet_mix32(h ^ (n * 0x85EBCA77u + 0x165667B1u));
+    h = fnet_mix32(h ^ (c * 0xC2B2AE3Du + 0x27D4EB2Fu));
+    const float u = (float)(h >> 8) * (1.0f / 16777216.0f);  // [0,1)
+    return u < p ? 0.f : 1.f / (1.f - p);
+}
+
+// ---------------------------------------------------------------- block reductions (256 threads = 4 waves)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+// host-side launch checking
+extern int g_fnet_last_hip_error;
+#define FNET_CHECK_ARG(cond)                     \
+    do {                                         \
+        if (!(cond)) return FNET_E_BADARG;       \
+    } while (0)
+#define FNET_LAUNCH_CHECK()                      \
+    do {                                         \
+        hipError_t e__ = hipGetLastError();      \
+        if (e__ != hipSuccess) {                 \
+            g_fnet_last_hip_error = (int)e__;    \
+            return FNET_E_HIP;                   \
+        }                                        \
+    } while (0)
+
+#define DISPATCH_T(dtype, ...)                                       \
+    if ((dtype) == FNET_BF16) { using T = bf16_t; __VA_ARGS__; }      \
+    else if ((dtype) == FNET_F32) { using T = float; __VA_ARGS__; }   \
+    else return FNET_E_BADARG;
+
+// op launchers (one per opcode), defined across the .hip files
+#define FNET_DECL_OP(name) int name(const FnetOp& op, hipStream_t st)
+FNET_DECL_OP(fnet_op_pack_input);
+FNET_DECL_OP(fnet_op_conv3x3);
+FNET_DECL_OP(fnet_op_wgrad);
+FNET_DECL_OP(fnet_op_in_stats);
+FNET_DECL_OP(fnet_op_apply);
+FNET_DECL_OP(fnet_op_upsample2x);
+FNET_DECL_OP(fnet_op_subsample_bias);
+FNET_DECL_OP(fnet_op_pad_ring);
+FNET_DECL_OP(fnet_op_head_fwd);
+FNET_DECL_OP(fnet_op_loss_reduce);
+FNET_DECL_OP(fnet_op_loss_finalize);
+FNET_DECL_OP(fnet_op_loss_grad);
+FNET_DECL_OP(fnet_op_head_bwd);
+FNET_DECL_OP(fnet_op_inact_bwd_reduce);
+FNET_DECL_OP(fnet_op_inact_bwd_apply);
+FNET_DECL_OP(fnet_op_affine_grad);
+FNET_DECL_OP(fnet_op_fold_sum);
+FNET_DECL_OP(fnet_op_bias_grad);
+FNET_DECL_OP(fnet_op_zero_insert);
+FNET_DECL_OP(fnet_op_upsample2x_bwd);
+FNET_DECL_OP(fnet_op_unpack_grad);
+FNET_DECL_OP(fnet_op_zero);
+FNET_DECL_OP(fnet_op_prep_weights);
+FNET_DECL_OP(fnet_op_grad_norm);
+FNET_DECL_OP(fnet_op_adam);
+FNET_DECL_OP(fnet_op_copy_planes);
+FNET_DECL_OP(fnet_op_unprep_wgrad);
+FNET_DECL_OP(fnet_op_stencil);
+
+// conv implementations (fnet_conv_ref.hip / fnet_conv_mfma.hip)
+int fnet_conv3x3_ref(const FnetOp& op, hipStream_t st);
+int fnet_conv3x3_mfma(const FnetOp& op, hipStream_t st);
+int fnet_wgrad_ref(const FnetOp& op, hipStream_t st);
+int fnet_wgrad_mfma(const FnetOp& op, hipStream_t st);

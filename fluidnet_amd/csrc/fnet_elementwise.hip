@@ -1,0 +1,719 @@
+// Bandwidth kernels of the UNet hot path: input packing, InstanceNorm statistics, the fused
+// norm+activation(+dropout)(+residual) "apply" pass and its two-pass adjoint, bilinear/nearest
+// upsampling and adjoint, stride-2 subsample / zero-insert, ring fill, gradient folding.
+//
+// All P-tensor kernels move 8 channels (16 B bf16 / 32 B fp32) per lane; a row of the padded
+// image is walked by consecutive lanes so global accesses coalesce (cdna guide G2/G13).
+// Grid convention for "row kernels": blockIdx.x = n*(H+2)+y (one padded row), blockIdx.y*256+tid
+// = x*(C/8)+cg within the row.
+#include "fnet_common.h"
+
+int g_fnet_last_hip_error = 0;
+
+namespace {
+
+constexpr int kThreads = 256;
+
+__device__ __forceinline__ void block_sum8(float (&v)[8], float* lds /* >= 8*4 floats */) {
+    // sum v[0..7] over the 256 threads of the block; result valid in all threads
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = wave_sum(v[k]);
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) lds[wave * 8 + k] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = lds[k] + lds[8 + k] + lds[16 + k] + lds[24 + k];
+}
+
+// ------------------------------------------------------------------ PACK_INPUT
+// dst[n,y,x,c] = plane_c[n, src(y), src(x)] for c < 6, 0 for c >= 6  (ring per padding mode)
+struct PackArgs {
+    const float* src[6];
+    int bstride[6];
+};
+template <typename T>
+__global__ __launch_bounds__(256) void k_pack_input(PackArgs a, T* dst, int B, int H, int W, int Cpad, int pm) {
+    const int Hp = H + 2, Wp = W + 2;
+    const int row = blockIdx.x;
+    const int n = row / Hp, y = row % Hp;
+    const int x = blockIdx.y * kThreads + threadIdx.x;
+    if (x >= Wp) return;
+    const int sy = pad_src(y - 1, H, pm), sx = pad_src(x - 1, W, pm);
+    T* d = dst + ((size_t)row * Wp + x) * Cpad;
+    for (int c = 0; c < Cpad; ++c) {
+        float v = 0.f;
+        if (c < 6 && sy >= 0 && sx >= 0) v = a.src[c][(size_t)n * a.bstride[c] + (size_t)sy * W + sx];
+        st1<T>(d + c, v);
+    }
+}
+
+// ------------------------------------------------------------------ IN_STATS
+// one block per (n, 8-channel group): exact two-pass mean / biased variance over the interior H*W
+template <typename T>
+__global__ __launch_bounds__(256) void k_in_stats(const T* raw, float2* stats, int B, int H, int W, int C, int ldc, int coff, float eps) {
+    __shared__ float red[32];
+    const int groups = C >> 3;
+    const int n = blockIdx.x / groups, cg = blockIdx.x % groups;
+    const int Wp = W + 2;
+    const size_t img = (size_t)n * (H + 2) * Wp;
+    const T* base = raw + coff + cg * 8;
+    const int HW = H * W;
+    float s[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s[k] = 0.f;
+    for (int idx = threadIdx.x; idx < HW; idx += kThreads) {
+        const int y = idx / W, x = idx - y * W;
+        Vec8<T> v;
+        v.load(base + (img + (size_t)(y + 1) * Wp + (x + 1)) * ldc);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s[k] += v.v[k];
+    }
+    block_sum8(s, red);
+    float mean[8], q[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { mean[k] = s[k] / (float)HW; q[k] = 0.f; }
+    for (int idx = threadIdx.x; idx < HW; idx += kThreads) {
+        const int y = idx / W, x = idx - y * W;
+        Vec8<T> v;
+        v.load(base + (img + (size_t)(y + 1) * Wp + (x + 1)) * ldc);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const float d = v.v[k] - mean[k]; q[k] += d * d; }
+    }
+    block_sum8(q, red);
+    if (threadIdx.x < 8) {
+        const int k = threadIdx.x;
+        float m = 0.f, qq = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) if (j == k) { m = mean[j]; qq = q[j]; }
+        stats[(size_t)n * C + cg * 8 + k] = make_float2(m, rsqrtf(qq / (float)HW + eps));
+    }
+}
+
+// ------------------------------------------------------------------ APPLY
+// dst[n,y,x,c] = act(gamma*(raw[src]-mean)*rstd+beta) * drop(n,c) + res[src], over the padded domain
+template <typename T>
+__global__ __launch_bounds__(256) void k_apply(const T* raw, const float2* stats, const float* gamma, const float* beta, const T* res, T* dst,
+                        int B, int H, int W, int C, int ldc_raw, int coff_raw, int ldc_res, int coff_res, int ldc_dst,
+                        int coff_dst, int act, int pm, uint32_t site, uint32_t seed, float drop_p) {
+    const int Hp = H + 2, Wp = W + 2, groups = C >> 3;
+    const int row = blockIdx.x;
+    const int n = row / Hp, y = row % Hp;
+    const int item = blockIdx.y * kThreads + threadIdx.x;
+    if (item >= Wp * groups) return;
+    const int x = item / groups, cg = item - x * groups;
+    const int c0 = cg * 8;
+    T* d = dst + ((size_t)row * Wp + x) * ldc_dst + coff_dst + c0;
+    const int sy = pad_src(y - 1, H, pm), sx = pad_src(x - 1, W, pm);
+    Vec8<T> o;
+    if (sy < 0 || sx < 0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o.v[k] = 0.f;
+        o.store(d);
+        return;
+    }
+    const size_t spix = ((size_t)n * Hp + sy + 1) * Wp + sx + 1;
+    Vec8<T> r;
+    r.load(raw + spix * ldc_raw + coff_raw + c0);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        float u = r.v[k];
+        if (stats) {
+            const float2 ms = stats[(size_t)n * C + c0 + k];
+            u = (u - ms.x) * ms.y * gamma[c0 + k] + beta[c0 + k];
+        }
+        o.v[k] = act_fwd(u, act) * drop_scale(seed, site, n, c0 + k, drop_p);
+    }
+    if (res) {
+        Vec8<T> q;
+        q.load(res + spix * ldc_res + coff_res + c0);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o.v[k] += q.v[k];
+    }
+    o.store(d);
+}
+
+// ------------------------------------------------------------------ gradient read with ring fold
+// Gradient of an interior pixel of a padded buffer = sum over all padded positions that copied it.
+template <typename T>
+__device__ __forceinline__ void fold_read8(const T* g, int n, int y, int x, int H, int W, int ldc, int pm, int fold,
+                                           float (&acc)[8]) {
+    const int Hp = H + 2, Wp = W + 2;
+    if (!fold) {
+        Vec8<T> v;
+        v.load(g + (((size_t)n * Hp + y + 1) * Wp + x + 1) * ldc);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] += v.v[k];
+        return;
+    }
+    int ys[3], xs[3];
+    const int ny = fold_list(y, H, pm, ys), nx = fold_list(x, W, pm, xs);
+    for (int a = 0; a < ny; ++a)
+        for (int b = 0; b < nx; ++b) {
+            Vec8<T> v;
+            v.load(g + (((size_t)n * Hp + ys[a]) * Wp + xs[b]) * ldc);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[k] += v.v[k];
+        }
+}
+
+// ------------------------------------------------------------------ INACT_BWD_REDUCE (pass 1)
+// G = fold(g1) + fold(g2); dz = G*drop*act'(u); S1 = sum dz, S2 = sum dz*xhat per (n,c).  Writes G (interior).
+template <typename T>
+__global__ __launch_bounds__(256) void k_inact_bwd_reduce(const T* g1, const T* g2, const T* raw, const float2* stats, const float* gamma,
+                                   const float* beta, T* G, float2* S, int B, int H, int W, int C, int ldc_g1,
+                                   int coff_g1, int ldc_g2, int coff_g2, int ldc_raw, int coff_raw, int ldc_G, int coff_G,
+                                   int fold1, int fold2, int act, int pm, uint32_t site, uint32_t seed, float drop_p) {
+    __shared__ float red[32];
+    const int groups = C >> 3;
+    const int n = blockIdx.x / groups, cg = blockIdx.x % groups, c0 = cg * 8;
+    const int Hp = H + 2, Wp = W + 2, HW = H * W;
+    float mean[8], rstd[8], gam[8], bet[8], dsc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float2 ms = stats[(size_t)n * C + c0 + k];
+        mean[k] = ms.x; rstd[k] = ms.y; gam[k] = gamma[c0 + k]; bet[k] = beta[c0 + k];
+        dsc[k] = drop_scale(seed, site, n, c0 + k, drop_p);
+    }
+    float s[8];  // interleave S1 (4) / S2 (4)? no: two separate reductions of 8
+    float t[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { s[k] = 0.f; t[k] = 0.f; }
+    for (int idx = threadIdx.x; idx < HW; idx += kThreads) {
+        const int y = idx / W, x = idx - y * W;
+        float acc[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+        fold_read8<T>(g1 + coff_g1 + c0, n, y, x, H, W, ldc_g1, pm, fold1, acc);
+        if (g2) fold_read8<T>(g2 + coff_g2 + c0, n, y, x, H, W, ldc_g2, pm, fold2, acc);
+        const size_t pix = ((size_t)n * Hp + y + 1) * Wp + x + 1;
+        Vec8<T> go;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) go.v[k] = acc[k];
+        go.store(G + pix * ldc_G + coff_G + c0);
+        Vec8<T> r;
+        r.load(raw + pix * ldc_raw + coff_raw + c0);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            // use the value as stored (bf16-rounded in bf16 mode) so that pass 2 sees the same G
+            const float xh = (r.v[k] - mean[k]) * rstd[k];
+            const float u = xh * gam[k] + bet[k];
+            float gq = go.v[k];
+            if (sizeof(T) == 2) gq = bf2f(f2bf(gq));
+            const float dz = gq * dsc[k] * act_bwd(u, act);
+            s[k] += dz;
+            t[k] += dz * xh;
+        }
+    }
+    block_sum8(s, red);
+    block_sum8(t, red);
+    if (threadIdx.x < 8) {
+        const int k = threadIdx.x;
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) if (j == k) { a = s[j]; b = t[j]; }
+        S[(size_t)n * C + c0 + k] = make_float2(a, b);
+    }
+}
+
+// ------------------------------------------------------------------ INACT_BWD_APPLY (pass 2)
+// d_raw = gamma*rstd*(dz - S1/HW - xhat*S2/HW) on the interior, 0 on the ring (so that d_raw can feed
+// the flattened dgrad / wgrad convolutions directly).
+template <typename T>
+__global__ __launch_bounds__(256) void k_inact_bwd_apply(const T* G, const T* raw, const float2* stats, const float* gamma, const float* beta,
+                                  const float2* S, T* draw, int B, int H, int W, int C, int ldc_G, int coff_G, int ldc_raw,
+                                  int coff_raw, int ldc_d, int coff_d, int act, uint32_t site, uint32_t seed, float drop_p) {
+    const int Hp = H + 2, Wp = W + 2, groups = C >> 3;
+    const int row = blockIdx.x;
+    const int n = row / Hp, y = row % Hp;
+    const int item = blockIdx.y * kThreads + threadIdx.x;
+    if (item >= Wp * groups) return;
+    const int x = item / groups, cg = item - x * groups, c0 = cg * 8;
+    const size_t pix = (size_t)row * Wp + x;
+    T* d = draw + pix * ldc_d + coff_d + c0;
+    Vec8<T> o;
+    if (y == 0 || y == Hp - 1 || x == 0 || x == Wp - 1) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o.v[k] = 0.f;
+        o.store(d);
+        return;
+    }
+    Vec8<T> g, r;
+    g.load(G + pix * ldc_G + coff_G + c0);
+    r.load(raw + pix * ldc_raw + coff_raw + c0);
+    const float inv = 1.f / (float)(H * W);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float2 ms = stats[(size_t)n * C + c0 + k];
+        const float2 ss = S[(size_t)n * C + c0 + k];
+        const float gm = gamma[c0 + k];
+        const float xh = (r.v[k] - ms.x) * ms.y;
+        const float u = xh * gm + beta[c0 + k];
+        const float dz = g.v[k] * drop_scale(seed, site, n, c0 + k, drop_p) * act_bwd(u, act);
+        o.v[k] = gm * ms.y * (dz - ss.x * inv - xh * ss.y * inv);
+    }
+    o.store(d);
+}
+
+// ------------------------------------------------------------------ AFFINE_GRAD: dgamma += sum_n S2, dbeta += sum_n S1
+__global__ __launch_bounds__(256) void k_affine_grad(const float2* S, float* dgamma, float* dbeta, int B, int C) {
+    const int c = blockIdx.x * kThreads + threadIdx.x;
+    if (c >= C) return;
+    float a = 0.f, b = 0.f;
+    for (int n = 0; n < B; ++n) {
+        const float2 s = S[(size_t)n * C + c];
+        a += s.x; b += s.y;
+    }
+    dbeta[c] += a;
+    dgamma[c] += b;
+}
+
+// ------------------------------------------------------------------ FOLD_SUM: dst = fold(g1)+fold(g2) interior, 0 ring
+template <typename T>
+__global__ __launch_bounds__(256) void k_fold_sum(const T* g1, const T* g2, T* dst, int B, int H, int W, int C, int ldc_g1, int coff_g1,
+                           int ldc_g2, int coff_g2, int ldc_d, int coff_d, int fold1, int fold2, int pm) {
+    const int Hp = H + 2, Wp = W + 2, groups = C >> 3;
+    const int row = blockIdx.x;
+    const int n = row / Hp, y = row % Hp;
+    const int item = blockIdx.y * kThreads + threadIdx.x;
+    if (item >= Wp * groups) return;
+    const int x = item / groups, cg = item - x * groups, c0 = cg * 8;
+    T* d = dst + ((size_t)row * Wp + x) * ldc_d + coff_d + c0;
+    Vec8<T> o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o.v[k] = 0.f;
+    if (!(y == 0 || y == Hp - 1 || x == 0 || x == Wp - 1)) {
+        fold_read8<T>(g1 + coff_g1 + c0, n, y - 1, x - 1, H, W, ldc_g1, pm, fold1, o.v);
+        if (g2) fold_read8<T>(g2 + coff_g2 + c0, n, y - 1, x - 1, H, W, ldc_g2, pm, fold2, o.v);
+    }
+    o.store(d);
+}
+
+// ------------------------------------------------------------------ BIAS_GRAD: dbias[c] += sum over n, interior
+template <typename T>
+__global__ __launch_bounds__(256) void k_bias_grad(const T* d, float* dbias, int B, int H, int W, int C, int ldc, int coff) {
+    __shared__ float red[32];
+    const int cg = blockIdx.x, c0 = cg * 8;
+    const int Hp = H + 2, Wp = W + 2, HW = H * W;
+    float s[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s[k] = 0.f;
+    const int total = B * HW;
+    for (int idx = blockIdx.y * kThreads + threadIdx.x; idx < total; idx += gridDim.y * kThreads) {
+        const int n = idx / HW, r = idx - n * HW, y = r / W, x = r - y * W;
+        Vec8<T> v;
+        v.load(d + (((size_t)n * Hp + y + 1) * Wp + x + 1) * ldc + coff + c0);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s[k] += v.v[k];
+    }
+    block_sum8(s, red);
+    if (threadIdx.x < 8) {
+        const int k = threadIdx.x;
+        float a = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) if (j == k) a = s[j];
+        atomicAdd(dbias + c0 + k, a);
+    }
+}
+
+// ------------------------------------------------------------------ UPSAMPLE2X (nn.Upsample(scale_factor=2), unet.py:152-156)
+// bilinear, align_corners=False: out[2a] = .25 in[a-1] + .75 in[a], out[2a+1] = .75 in[a] + .25 in[a+1], edges clamped.
+__device__ __forceinline__ void up_taps(int Y, int h, int mode, int& i0, int& i1, float& w0, float& w1) {
+    const int a = Y >> 1;
+    if (mode == 0) { i0 = i1 = a; w0 = 1.f; w1 = 0.f; return; }
+    if (Y & 1) { i0 = a; i1 = min(a + 1, h - 1); w0 = 0.75f; w1 = 0.25f; }
+    else { i0 = max(a - 1, 0); i1 = a; w0 = 0.25f; w1 = 0.75f; }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_upsample2x(const T* src, T* dst, int B, int h, int w, int C, int ldc_s, int coff_s, int ldc_d, int coff_d,
+                             int mode, int pm) {
+    const int H = 2 * h, W = 2 * w, Hp = H + 2, Wp = W + 2, groups = C >> 3;
+    const int row = blockIdx.x;
+    const int n = row / Hp, y = row % Hp;
+    const int item = blockIdx.y * kThreads + threadIdx.x;
+    if (item >= Wp * groups) return;
+    const int x = item / groups, cg = item - x * groups, c0 = cg * 8;
+    T* d = dst + ((size_t)row * Wp + x) * ldc_d + coff_d + c0;
+    const int Y = pad_src(y - 1, H, pm), X = pad_src(x - 1, W, pm);
+    Vec8<T> o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o.v[k] = 0.f;
+    if (Y >= 0 && X >= 0) {
+        int y0, y1, x0, x1;
+        float wy0, wy1, wx0, wx1;
+        up_taps(Y, h, mode, y0, y1, wy0, wy1);
+        up_taps(X, w, mode, x0, x1, wx0, wx1);
+        const int hp = h + 2, wp = w + 2;
+        const T* s = src + coff_s + c0;
+        const size_t img = (size_t)n * hp;
+        Vec8<T> a, b, c, e;
+        a.load(s + ((img + y0 + 1) * wp + x0 + 1) * ldc_s);
+        b.load(s + ((img + y0 + 1) * wp + x1 + 1) * ldc_s);
+        c.load(s + ((img + y1 + 1) * wp + x0 + 1) * ldc_s);
+        e.load(s + ((img + y1 + 1) * wp + x1 + 1) * ldc_s);
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            o.v[k] = wy0 * (wx0 * a.v[k] + wx1 * b.v[k]) + wy1 * (wx0 * c.v[k] + wx1 * e.v[k]);
+    }
+    o.store(d);
+}
+
+// adjoint: dst[n,i,j] = sum_{Y,X} wy(Y,i) wx(X,j) fold(g)[Y,X]   (dst interior only)
+__device__ __forceinline__ int up_adj(int i, int h, int mode, int Ys[4], float ws[4]) {
+    int k = 0;
+    if (mode == 0) { Ys[0] = 2 * i; ws[0] = 1.f; Ys[1] = 2 * i + 1; ws[1] = 1.f; return 2; }
+    Ys[k] = 2 * i; ws[k++] = (i == 0) ? 1.0f : 0.75f;
+    Ys[k] = 2 * i + 1; ws[k++] = (i == h - 1) ? 1.0f : 0.75f;
+    if (i >= 1) { Ys[k] = 2 * i - 1; ws[k++] = 0.25f; }
+    if (i + 1 <= h - 1) { Ys[k] = 2 * i + 2; ws[k++] = 0.25f; }
+    return k;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_upsample2x_bwd(const T* g, T* dst, int B, int h, int w, int C, int ldc_g, int coff_g, int ldc_d, int coff_d,
+                                 int fold, int mode, int pm) {
+    const int hp = h + 2, wp = w + 2, groups = C >> 3;
+    const int row = blockIdx.x;  // n*h + i  (interior rows only)
+    const int n = row / h, i = row % h;
+    const int item = blockIdx.y * kThreads + threadIdx.x;
+    if (item >= w * groups) return;
+    const int j = item / groups, cg = item - j * groups, c0 = cg * 8;
+    int Ys[4], Xs[4];
+    float wy[4], wx[4];
+    const int ny = up_adj(i, h, mode, Ys, wy), nx = up_adj(j, w, mode, Xs, wx);
+    Vec8<T> o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o.v[k] = 0.f;
+    for (int a = 0; a < ny; ++a)
+        for (int b = 0; b < nx; ++b) {
+            float acc[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+            fold_read8<T>(g + coff_g + c0, n, Ys[a], Xs[b], 2 * h, 2 * w, ldc_g, pm, fold, acc);
+            const float ww = wy[a] * wx[b];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o.v[k] += ww * acc[k];
+        }
+    o.store(dst + (((size_t)n * hp + i + 1) * wp + j + 1) * ldc_d + coff_d + c0);
+}
+
+// ------------------------------------------------------------------ SUBSAMPLE_BIAS (stride-2 conv = stride-1 conv sampled at even pixels)
+template <typename T>
+__global__ __launch_bounds__(256) void k_subsample_bias(const T* src, const float* bias, T* dst, int B, int H, int W, int C, int ldc_s, int coff_s,
+                                 int ldc_d, int coff_d, int pm) {
+    const int h = H / 2, w = W / 2, hp = h + 2, wp = w + 2, groups = C >> 3;
+    const int row = blockIdx.x;
+    const int n = row / hp, y = row % hp;
+    const int item = blockIdx.y * kThreads + threadIdx.x;
+    if (item >= wp * groups) return;
+    const int x = item / groups, cg = item - x * groups, c0 = cg * 8;
+    T* d = dst + ((size_t)row * wp + x) * ldc_d + coff_d + c0;
+    const int i = pad_src(y - 1, h, pm), j = pad_src(x - 1, w, pm);
+    Vec8<T> o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o.v[k] = 0.f;
+    if (i >= 0 && j >= 0) {
+        o.load(src + (((size_t)n * (H + 2) + 2 * i + 1) * (W + 2) + 2 * j + 1) * ldc_s + coff_s + c0);
+        if (bias) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o.v[k] += bias[c0 + k];
+        }
+    }
+    o.store(d);
+}
+
+// ------------------------------------------------------------------ ZERO_INSERT (adjoint of the even-pixel sampling)
+template <typename T>
+__global__ __launch_bounds__(256) void k_zero_insert(const T* src, T* dst, int B, int h, int w, int C, int ldc_s, int coff_s, int ldc_d, int coff_d) {
+    const int H = 2 * h, W = 2 * w, Hp = H + 2, Wp = W + 2, groups = C >> 3;
+    const int row = blockIdx.x;
+    const int n = row / Hp, y = row % Hp;
+    const int item = blockIdx.y * kThreads + threadIdx.x;
+    if (item >= Wp * groups) return;
+    const int x = item / groups, cg = item - x * groups, c0 = cg * 8;
+    Vec8<T> o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o.v[k] = 0.f;
+    // padded (y,x) = (2i+1, 2j+1) <-> half-res interior (i,j)
+    if ((y & 1) && (x & 1) && y < Hp - 1 && x < Wp - 1) {
+        const int i = (y - 1) >> 1, j = (x - 1) >> 1;
+        o.load(src + (((size_t)n * (h + 2) + i + 1) * (w + 2) + j + 1) * ldc_s + coff_s + c0);
+    }
+    o.store(dst + ((size_t)row * Wp + x) * ldc_d + coff_d + c0);
+}
+
+// ------------------------------------------------------------------ PAD_RING (in place)
+template <typename T>
+__global__ __launch_bounds__(256) void k_pad_ring(T* buf, int B, int H, int W, int C, int ldc, int coff, int pm) {
+    const int Hp = H + 2, Wp = W + 2, groups = C >> 3;
+    const int ring = 2 * Wp + 2 * H;  // ring pixels per image
+    const int n = blockIdx.x;
+    const int item = blockIdx.y * kThreads + threadIdx.x;
+    if (item >= ring * groups) return;
+    const int r = item / groups, cg = item - r * groups, c0 = cg * 8;
+    int y, x;
+    if (r < Wp) { y = 0; x = r; }
+    else if (r < 2 * Wp) { y = Hp - 1; x = r - Wp; }
+    else if (r < 2 * Wp + H) { y = r - 2 * Wp + 1; x = 0; }
+    else { y = r - 2 * Wp - H + 1; x = Wp - 1; }
+    const int sy = pad_src(y - 1, H, pm), sx = pad_src(x - 1, W, pm);
+    Vec8<T> o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o.v[k] = 0.f;
+    T* base = buf + coff + c0;
+    if (sy >= 0 && sx >= 0) o.load(base + (((size_t)n * Hp + sy + 1) * Wp + sx + 1) * ldc);
+    o.store(base + (((size_t)n * Hp + y) * Wp + x) * ldc);
+}
+
+// ------------------------------------------------------------------ UNPACK_GRAD: dx[n,c,y,x] = fold(d_in_pad)[n,y,x,c]
+template <typename T>
+__global__ __launch_bounds__(256) void k_unpack_grad(const T* g, float* dx, int B, int H, int W, int ldc, int nch, int pm) {
+    const int row = blockIdx.x;  // n*H + y
+    const int n = row / H, y = row % H;
+    const int x = blockIdx.y * kThreads + threadIdx.x;
+    if (x >= W) return;
+    float acc[8];
+    for (int c0 = 0; c0 < nch; c0 += 8) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+        fold_read8<T>(g + c0, n, y, x, H, W, ldc, pm, 1, acc);
+        for (int k = 0; k < 8 && c0 + k < nch; ++k) dx[(((size_t)n * nch + c0 + k) * H + y) * W + x] = acc[k];
+    }
+}
+
+// ------------------------------------------------------------------ COPY_PLANES: dst[n, :] = src[n, :] (count floats per n, strided batches)
+__global__ __launch_bounds__(256) void k_copy_planes(const float* src, float* dst, int B, int count, int sstride, int dstride) {
+    const int n = blockIdx.y;
+    for (int i = blockIdx.x * kThreads + threadIdx.x; i < count; i += gridDim.x * kThreads)
+        dst[(size_t)n * dstride + i] = src[(size_t)n * sstride + i];
+}
+
+inline dim3 row_grid(int rows, int items) { return dim3(rows, (items + kThreads - 1) / kThreads, 1); }
+inline bool vec_ok(const void* p, int ldc, int coff, int C, int dtype) {
+    const int esz = dtype == FNET_BF16 ? 2 : 4;
+    return p != nullptr && (C % 8) == 0 && (ldc % 8) == 0 && (coff % 8) == 0 && C > 0 && coff + C <= ldc &&
+           (((uintptr_t)p) % (8 * esz)) == 0;
+}
+inline bool vec_ok_opt(const void* p, int ldc, int coff, int C, int dtype) { return p == nullptr || vec_ok(p, ldc, coff, C, dtype); }
+
+}  // namespace
+
+// PACK_INPUT  i: 0 B,1 H,2 W,3 Cpad,4 pm,5..10 batch strides of the six planes (elements)
+//             p: 0..5 source planes fp32 (plane n at src + n*stride, H*W contiguous), 6 dst P[B,H+2,W+2,Cpad]
+int fnet_op_pack_input(const FnetOp& op, hipStream_t st) {
+    const int B = op.i[0], H = op.i[1], W = op.i[2], Cpad = op.i[3], pm = op.i[4];
+    FNET_CHECK_ARG(B > 0 && H >= 2 && W >= 2 && Cpad >= 6 && Cpad % 8 == 0 && pm >= 0 && pm <= 3 && op.p[6]);
+    PackArgs a;
+    for (int c = 0; c < 6; ++c) {
+        FNET_CHECK_ARG(op.p[c] != 0 && op.i[5 + c] >= H * W);
+        a.src[c] = (const float*)op.p[c];
+        a.bstride[c] = op.i[5 + c];
+    }
+    DISPATCH_T(op.dtype, hipLaunchKernelGGL(k_pack_input<T>, row_grid(B * (H + 2), W + 2), dim3(kThreads), 0, st, a,
+                                            (T*)op.p[6], B, H, W, Cpad, pm));
+    FNET_LAUNCH_CHECK();
+    return FNET_OK;
+}
+
+// IN_STATS  i: 0 B,1 H,2 W,3 C,4 ldc,5 coff; f: 0 eps; p: 0 raw, 1 stats float2[B][C] = (mean, rstd)
+int fnet_op_in_stats(const FnetOp& op, hipStream_t st) {
+    const int B = op.i[0], H = op.i[1], W = op.i[2], C = op.i[3];
+    FNET_CHECK_ARG(B > 0 && H > 0 && W > 0 && vec_ok((void*)op.p[0], op.i[4], op.i[5], C, op.dtype) && op.p[1]);
+    DISPATCH_T(op.dtype, hipLaunchKernelGGL(k_in_stats<T>, dim3(B * (C / 8)), dim3(kThreads), 0, st, (const T*)op.p[0],
+                                            (float2*)op.p[1], B, H, W, C, op.i[4], op.i[5], op.f[0]));
+    FNET_LAUNCH_CHECK();
+    return FNET_OK;
+}
+
+// APPLY  i: 0 B,1 H,2 W,3 C,4 ldc_raw,5 coff_raw,6 ldc_res,7 coff_res,8 ldc_dst,9 coff_dst,10 act,11 pm,12 drop site,13 seed
+//        f: 0 drop_p; p: 0 raw,1 stats|0,2 gamma|0,3 beta|0,4 res|0,5 dst
+int fnet_op_apply(const FnetOp& op, hipStream_t st) {
+    const int B = op.i[0], H = op.i[1], W = op.i[2], C = op.i[3];
+    FNET_CHECK_ARG(B > 0 && H >= 2 && W >= 2);
+    FNET_CHECK_ARG(vec_ok((void*)op.p[0], op.i[4], op.i[5], C, op.dtype));
+    FNET_CHECK_ARG(vec_ok_opt((void*)op.p[4], op.i[6], op.i[7], C, op.dtype));
+    FNET_CHECK_ARG(vec_ok((void*)op.p[5], op.i[8], op.i[9], C, op.dtype));
+    FNET_CHECK_ARG(op.i[10] >= 0 && op.i[10] <= 4 && op.i[11] >= 0 && op.i[11] <= 3);
+    FNET_CHECK_ARG(op.p[1] == 0 || (op.p[2] != 0 && op.p[3] != 0));
+    FNET_CHECK_ARG(op.f[0] >= 0.f && op.f[0] < 1.f);
+    DISPATCH_T(op.dtype, hipLaunchKernelGGL(k_apply<T>, row_grid(B * (H + 2), (W + 2) * (C / 8)), dim3(kThreads), 0, st,
+                                            (const T*)op.p[0], (const float2*)op.p[1], (const float*)op.p[2],
+                                            (const float*)op.p[3], (const T*)op.p[4], (T*)op.p[5], B, H, W, C, op.i[4],
+                                            op.i[5], op.i[6], op.i[7], op.i[8], op.i[9], op.i[10], op.i[11],
+                                            (uint32_t)op.i[12], (uint32_t)op.i[13], op.f[0]));
+    FNET_LAUNCH_CHECK();
+    return FNET_OK;
+}
+
+// INACT_BWD_REDUCE  i: 0 B,1 H,2 W,3 C,4 ldc_g1,5 coff_g1,6 ldc_g2,7 coff_g2,8 ldc_raw,9 coff_raw,10 ldc_G,11 coff_G,
+//                      12 fold1,13 fold2,14 act,15 pm,16 drop site,17 seed; f: 0 drop_p
+//                   p: 0 g1,1 g2|0,2 raw,3 stats,4 gamma,5 beta,6 G out,7 S out float2[B][C]
+int fnet_op_inact_bwd_reduce(const FnetOp& op, hipStream_t st) {
+    const int B = op.i[0], H = op.i[1], W = op.i[2], C = op.i[3];
+    FNET_CHECK_ARG(B > 0 && H >= 2 && W >= 2);
+    FNET_CHECK_ARG(vec_ok((void*)op.p[0], op.i[4], op.i[5], C, op.dtype));
+    FNET_CHECK_ARG(vec_ok_opt((void*)op.p[1], op.i[6], op.i[7], C, op.dtype));
+    FNET_CHECK_ARG(vec_ok((void*)op.p[2], op.i[8], op.i[9], C, op.dtype));
+    FNET_CHECK_ARG(vec_ok((void*)op.p[6], op.i[10], op.i[11], C, op.dtype));
+    FNET_CHECK_ARG(op.p[3] && op.p[4] && op.p[5] && op.p[7]);
+    DISPATCH_T(op.dtype,
+               hipLaunchKernelGGL(k_inact_bwd_reduce<T>, dim3(B * (C / 8)), dim3(kThreads), 0, st, (const T*)op.p[0],
+                                  (const T*)op.p[1], (const T*)op.p[2], (const float2*)op.p[3], (const float*)op.p[4],
+                                  (const float*)op.p[5], (T*)op.p[6], (float2*)op.p[7], B, H, W, C, op.i[4], op.i[5],
+                                  op.i[6], op.i[7], op.i[8], op.i[9], op.i[10], op.i[11], op.i[12], op.i[13], op.i[14],
+                                  op.i[15], (uint32_t)op.i[16], (uint32_t)op.i[17], op.f[0]));
+    FNET_LAUNCH_CHECK();
+    return FNET_OK;
+}
+
+// INACT_BWD_APPLY  i: 0 B,1 H,2 W,3 C,4 ldc_G,5 coff_G,6 ldc_raw,7 coff_raw,8 ldc_d,9 coff_d,10 act,11 drop site,12 seed
+//                  f: 0 drop_p; p: 0 G,1 raw,2 stats,3 gamma,4 beta,5 S,6 d_raw out
+int fnet_op_inact_bwd_apply(const FnetOp& op, hipStream_t st) {
+    const int B = op.i[0], H = op.i[1], W = op.i[2], C = op.i[3];
+    FNET_CHECK_ARG(B > 0 && H >= 2 && W >= 2);
+    FNET_CHECK_ARG(vec_ok((void*)op.p[0], op.i[4], op.i[5], C, op.dtype));
+    FNET_CHECK_ARG(vec_ok((void*)op.p[1], op.i[6], op.i[7], C, op.dtype));
+    FNET_CHECK_ARG(vec_ok((void*)op.p[6], op.i[8], op.i[9], C, op.dtype));
+    FNET_CHECK_ARG(op.p[2] && op.p[3] && op.p[4] && op.p[5]);
+    DISPATCH_T(op.dtype, hipLaunchKernelGGL(k_inact_bwd_apply<T>, row_grid(B * (H + 2), (W + 2) * (C / 8)), dim3(kThreads), 0,
+                                            st, (const T*)op.p[0], (const T*)op.p[1], (const float2*)op.p[2],
+                                            (const float*)op.p[3], (const float*)op.p[4], (const float2*)op.p[5],
+                                            (T*)op.p[6], B, H, W, C, op.i[4], op.i[5], op.i[6], op.i[7], op.i[8], op.i[9],
+                                            op.i[10], (uint32_t)op.i[11], (uint32_t)op.i[12], op.f[0]));
+    FNET_LAUNCH_CHECK();
+    return FNET_OK;
+}
+
+// AFFINE_GRAD  i: 0 B,1 C; p: 0 S float2[B][C],1 dgamma (+=),2 dbeta (+=)
+int fnet_op_affine_grad(const FnetOp& op, hipStream_t st) {
+    const int B = op.i[0], C = op.i[1];
+    FNET_CHECK_ARG(B > 0 && C > 0 && op.p[0] && op.p[1] && op.p[2]);
+    hipLaunchKernelGGL(k_affine_grad, dim3((C + kThreads - 1) / kThreads), dim3(kThreads), 0, st, (const float2*)op.p[0],
+                       (float*)op.p[1], (float*)op.p[2], B, C);
+    FNET_LAUNCH_CHECK();
+    return FNET_OK;
+}
+
+// FOLD_SUM  i: 0 B,1 H,2 W,3 C,4 ldc_g1,5 coff_g1,6 ldc_g2,7 coff_g2,8 ldc_d,9 coff_d,10 fold1,11 fold2,12 pm
+//           p: 0 g1,1 g2|0,2 dst (interior = folded sum, ring = 0)
+int fnet_op_fold_sum(const FnetOp& op, hipStream_t st) {
+    const int B = op.i[0], H = op.i[1], W = op.i[2], C = op.i[3];
+    FNET_CHECK_ARG(B > 0 && H >= 2 && W >= 2);
+    FNET_CHECK_ARG(vec_ok((void*)op.p[0], op.i[4], op.i[5], C, op.dtype));
+    FNET_CHECK_ARG(vec_ok_opt((void*)op.p[1], op.i[6], op.i[7], C, op.dtype));
+    FNET_CHECK_ARG(vec_ok((void*)op.p[2], op.i[8], op.i[9], C, op.dtype));
+    DISPATCH_T(op.dtype, hipLaunchKernelGGL(k_fold_sum<T>, row_grid(B * (H + 2), (W + 2) * (C / 8)), dim3(kThreads), 0, st,
+                                            (const T*)op.p[0], (const T*)op.p[1], (T*)op.p[2], B, H, W, C, op.i[4], op.i[5],
+                                            op.i[6], op.i[7], op.i[8], op.i[9], op.i[10], op.i[11], op.i[12]));
+    FNET_LAUNCH_CHECK();
+    return FNET_OK;
+}
+
+// BIAS_GRAD  i: 0 B,1 H,2 W,3 C,4 ldc,5 coff; p: 0 d (P),1 dbias (+=, atomics)
+int fnet_op_bias_grad(const FnetOp& op, hipStream_t st) {
+    const int B = op.i[0], H = op.i[1], W = op.i[2], C = op.i[3];
+    FNET_CHECK_ARG(B > 0 && H > 0 && W > 0 && vec_ok((void*)op.p[0], op.i[4], op.i[5], C, op.dtype) && op.p[1]);
+    int split = (B * H * W + kThreads * 16 - 1) / (kThreads * 16);
+    if (split < 1) split = 1;
+    if (split > 128) split = 128;
+    DISPATCH_T(op.dtype, hipLaunchKernelGGL(k_bias_grad<T>, dim3(C / 8, split), dim3(kThreads), 0, st, (const T*)op.p[0],
+                                            (float*)op.p[1], B, H, W, C, op.i[4], op.i[5]));
+    FNET_LAUNCH_CHECK();
+    return FNET_OK;
+}
+
+// UPSAMPLE2X  i: 0 B,1 h,2 w,3 C,4 ldc_s,5 coff_s,6 ldc_d,7 coff_d,8 mode (0 nearest,1 bilinear),9 pm; p: 0 src (h,w),1 dst (2h,2w)
+int fnet_op_upsample2x(const FnetOp& op, hipStream_t st) {
+    const int B = op.i[0], h = op.i[1], w = op.i[2], C = op.i[3];
+    FNET_CHECK_ARG(B > 0 && h >= 1 && w >= 1 && (op.i[8] == 0 || op.i[8] == 1));
+    FNET_CHECK_ARG(vec_ok((void*)op.p[0], op.i[4], op.i[5], C, op.dtype));
+    FNET_CHECK_ARG(vec_ok((void*)op.p[1], op.i[6], op.i[7], C, op.dtype));
+    DISPATCH_T(op.dtype, hipLaunchKernelGGL(k_upsample2x<T>, row_grid(B * (2 * h + 2), (2 * w + 2) * (C / 8)), dim3(kThreads),
+                                            0, st, (const T*)op.p[0], (T*)op.p[1], B, h, w, C, op.i[4], op.i[5], op.i[6],
+                                            op.i[7], op.i[8], op.i[9]));
+    FNET_LAUNCH_CHECK();
+    return FNET_OK;
+}
+
+// UPSAMPLE2X_BWD  i: 0 B,1 h,2 w,3 C,4 ldc_g,5 coff_g,6 ldc_d,7 coff_d,8 fold,9 mode,10 pm; p: 0 g (2h,2w),1 dst (h,w interior)
+int fnet_op_upsample2x_bwd(const FnetOp& op, hipStream_t st) {
+    const int B = op.i[0], h = op.i[1], w = op.i[2], C = op.i[3];
+    FNET_CHECK_ARG(B > 0 && h >= 1 && w >= 1 && (op.i[9] == 0 || op.i[9] == 1));
+    FNET_CHECK_ARG(vec_ok((void*)op.p[0], op.i[4], op.i[5], C, op.dtype));
+    FNET_CHECK_ARG(vec_ok((void*)op.p[1], op.i[6], op.i[7], C, op.dtype));
+    DISPATCH_T(op.dtype, hipLaunchKernelGGL(k_upsample2x_bwd<T>, row_grid(B * h, w * (C / 8)), dim3(kThreads), 0, st,
+                                            (const T*)op.p[0], (T*)op.p[1], B, h, w, C, op.i[4], op.i[5], op.i[6], op.i[7],
+                                            op.i[8], op.i[9], op.i[10]));
+    FNET_LAUNCH_CHECK();
+    return FNET_OK;
+}
+
+// SUBSAMPLE_BIAS  i: 0 B,1 H,2 W,3 C,4 ldc_s,5 coff_s,6 ldc_d,7 coff_d,8 pm; p: 0 src (H,W),1 bias|0,2 dst (H/2,W/2)
+int fnet_op_subsample_bias(const FnetOp& op, hipStream_t st) {
+    const int B = op.i[0], H = op.i[1], W = op.i[2], C = op.i[3];
+    FNET_CHECK_ARG(B > 0 && H >= 2 && W >= 2 && H % 2 == 0 && W % 2 == 0);
+    FNET_CHECK_ARG(vec_ok((void*)op.p[0], op.i[4], op.i[5], C, op.dtype));
+    FNET_CHECK_ARG(vec_ok((void*)op.p[2], op.i[6], op.i[7], C, op.dtype));
+    DISPATCH_T(op.dtype, hipLaunchKernelGGL(k_subsample_bias<T>, row_grid(B * (H / 2 + 2), (W / 2 + 2) * (C / 8)),
+                                            dim3(kThreads), 0, st, (const T*)op.p[0], (const float*)op.p[1], (T*)op.p[2], B, H,
+                                            W, C, op.i[4], op.i[5], op.i[6], op.i[7], op.i[8]));
+    FNET_LAUNCH_CHECK();
+    return FNET_OK;
+}
+
+// ZERO_INSERT  i: 0 B,1 h,2 w,3 C,4 ldc_s,5 coff_s,6 ldc_d,7 coff_d; p: 0 src (h,w),1 dst (2h,2w, whole padded domain written)
+int fnet_op_zero_insert(const FnetOp& op, hipStream_t st) {
+    const int B = op.i[0], h = op.i[1], w = op.i[2], C = op.i[3];
+    FNET_CHECK_ARG(B > 0 && h >= 1 && w >= 1);
+    FNET_CHECK_ARG(vec_ok((void*)op.p[0], op.i[4], op.i[5], C, op.dtype));
+    FNET_CHECK_ARG(vec_ok((void*)op.p[1], op.i[6], op.i[7], C, op.dtype));
+    DISPATCH_T(op.dtype, hipLaunchKernelGGL(k_zero_insert<T>, row_grid(B * (2 * h + 2), (2 * w + 2) * (C / 8)), dim3(kThreads),
+                                            0, st, (const T*)op.p[0], (T*)op.p[1], B, h, w, C, op.i[4], op.i[5], op.i[6],
+                                            op.i[7]));
+    FNET_LAUNCH_CHECK();
+    return FNET_OK;
+}
+
+// PAD_RING  i: 0 B,1 H,2 W,3 C,4 ldc,5 coff,6 pm; p: 0 buf (in place)
+int fnet_op_pad_ring(const FnetOp& op, hipStream_t st) {
+    const int B = op.i[0], H = op.i[1], W = op.i[2], C = op.i[3];
+    FNET_CHECK_ARG(B > 0 && H >= 2 && W >= 2 && vec_ok((void*)op.p[0], op.i[4], op.i[5], C, op.dtype));
+    const int items = (2 * (W + 2) + 2 * H) * (C / 8);
+    DISPATCH_T(op.dtype, hipLaunchKernelGGL(k_pad_ring<T>, dim3(B, (items + kThreads - 1) / kThreads), dim3(kThreads), 0, st,
+                                            (T*)op.p[0], B, H, W, C, op.i[4], op.i[5], op.i[6]));
+    FNET_LAUNCH_CHECK();
+    return FNET_OK;
+}
+
+// UNPACK_GRAD  i: 0 B,1 H,2 W,3 ldc,4 nch,5 pm; p: 0 d_in_pad (P),1 dx fp32 [B,nch,H,W]
+int fnet_op_unpack_grad(const FnetOp& op, hipStream_t st) {
+    const int B = op.i[0], H = op.i[1], W = op.i[2], ldc = op.i[3], nch = op.i[4];
+    FNET_CHECK_ARG(B > 0 && H >= 2 && W >= 2 && ldc % 8 == 0 && nch > 0 && nch <= ldc && op.p[0] && op.p[1]);
+    DISPATCH_T(op.dtype, hipLaunchKernelGGL(k_unpack_grad<T>, row_grid(B * H, W), dim3(kThreads), 0, st, (const T*)op.p[0],
+                                            (float*)op.p[1], B, H, W, ldc, nch, op.i[5]));
+    FNET_LAUNCH_CHECK();
+    return FNET_OK;
+}
+
+// COPY_PLANES  i: 0 B,1 count,2 src batch stride,3 dst batch stride (floats); p: 0 src,1 dst
+int fnet_op_copy_planes(const FnetOp& op, hipStream_t st) {
+    const int B = op.i[0], count = op.i[1];
+    FNET_CHECK_ARG(B > 0 && B < 65536 && count > 0 && op.p[0] && op.p[1]);
+    int gx = (count + kThreads * 4 - 1) / (kThreads * 4);
+    if (gx > 1024) gx = 1024;
+    hipLaunchKernelGGL(k_copy_planes, dim3(gx, B), dim3(kThreads), 0, st, (const float*)op.p[0], (float*)op.p[1], B, count,
+                       op.i[2], op.i[3]);
+    FNET_LAUNCH_CHECK();
+    return FNET_OK;
+}
+
+// ZERO  i: 0 = bytes & 0x7fffffff, 1 = bytes >> 31; p: 0 ptr
+int fnet_op_zero(const FnetOp& op, hipStream_t st) {
+    const size_t bytes = (size_t)op.i[0] + ((size_t)op.i[1] << 31);
+    FNET_CHECK_ARG(op.p[0] != 0 && bytes > 0);
+    hipError_t e = hipMemsetAsync((void*)op.p[0], 0, bytes, st);
+    if (e != hipSuccess) { g_fnet_last_hip_error = (int)e; return FNET_E_HIP; }
+    return FNET_OK;
+}

@@ -1,0 +1,461 @@
+// Physics loss (ml/training/physics_loss.py) forward reduction + analytic gradient, the 1x1 head conv with
+// its output activation (ml/models/unet.py:294-303), and the finite-difference stencils as free functions.
+// All field planes are fp32 NCHW exactly like the reference's tensors; reductions are wavefront-64 shuffles,
+// one double atomic per block.
+#include "fnet_common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr float kLossEps = 1e-8f;  // physics_loss.py:101,136
+
+struct Plane {
+    const float* p;
+    int bstride;  // elements between batch items
+};
+
+// value of the (conceptually padded) plane at (y,x), y in [-1,H], x in [-1,W]
+__device__ __forceinline__ float pat(const float* pl, int y, int x, int H, int W, int pm) {
+    const int sy = pad_src(y, H, pm), sx = pad_src(x, W, pm);
+    if (sy < 0 || sx < 0) return 0.f;
+    return pl[(size_t)sy * W + sx];
+}
+// d/dx and d/dy of plane pl at interior (y,x)   (physics_loss.py:35-44)
+__device__ __forceinline__ float ddx(const float* pl, int y, int x, int H, int W, int pm, int stencil, float dx) {
+    if (stencil == FNET_STENCIL_FORWARD) return (pat(pl, y, x + 1, H, W, pm) - pl[(size_t)y * W + x]) / dx;
+    return (pat(pl, y, x + 1, H, W, pm) - pat(pl, y, x - 1, H, W, pm)) / (2.0f * dx);
+}
+__device__ __forceinline__ float ddy(const float* pl, int y, int x, int H, int W, int pm, int stencil, float dy) {
+    if (stencil == FNET_STENCIL_FORWARD) return (pat(pl, y + 1, x, H, W, pm) - pl[(size_t)y * W + x]) / dy;
+    return (pat(pl, y + 1, x, H, W, pm) - pat(pl, y - 1, x, H, W, pm)) / (2.0f * dy);
+}
+__device__ __forceinline__ float sgn(float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); }
+
+struct LossArgs {
+    const float* pred;    // [B,3,H,W] contiguous
+    Plane tgt;            // 3 planes per item, contiguous within the item
+    Plane in0, emit, coll;
+    int B, H, W, pm, stencil, flags;  // flags: bit0 divergence, bit1 gradient, bit2 emitter
+    float dx;
+};
+
+__device__ __forceinline__ float fluid_at(const LossArgs& a, int n, int y, int x) {
+    const size_t o = (size_t)y * a.W + x;
+    return (a.emit.p[(size_t)n * a.emit.bstride + o] == 0.f && a.coll.p[(size_t)n * a.coll.bstride + o] == 0.f) ? 1.f : 0.f;
+}
+
+// sums[0]=sum (p-t)^2, [1]=sum |div| fluid, [2]=sum |gx_p-gx_t| fluid, [3]=same for y, [4]=sum d_pred*forbidden, [5]=sum fluid
+__global__ __launch_bounds__(256) void k_loss_reduce(LossArgs a, double* sums) {
+    __shared__ double red[4 * 6];
+    const int HW = a.H * a.W, total = a.B * HW;
+    double s[6] = {0, 0, 0, 0, 0, 0};
+    for (int idx = blockIdx.x * kThreads + threadIdx.x; idx < total; idx += gridDim.x * kThreads) {
+        const int n = idx / HW, r = idx - n * HW, y = r / a.W, x = r - y * a.W;
+        const float* P = a.pred + (size_t)n * 3 * HW;
+        const float* T = a.tgt.p + (size_t)n * a.tgt.bstride;
+        float e = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { const float d = P[c * HW + r] - T[c * HW + r]; e += d * d; }
+        s[0] += e;
+        const float fl = fluid_at(a, n, y, x);
+        s[5] += fl;
+        if (a.flags & 1) {
+            const float dv = ddx(P + HW, y, x, a.H, a.W, a.pm, a.stencil, a.dx) + ddy(P + 2 * HW, y, x, a.H, a.W, a.pm, a.stencil, a.dx);
+            s[1] += fabsf(dv) * fl;
+        }
+        if (a.flags & 2) {
+            const float gx = ddx(P, y, x, a.H, a.W, a.pm, a.stencil, a.dx) - ddx(T, y, x, a.H, a.W, a.pm, a.stencil, a.dx);
+            const float gy = ddy(P, y, x, a.H, a.W, a.pm, a.stencil, a.dx) - ddy(T, y, x, a.H, a.W, a.pm, a.stencil, a.dx);
+            s[2] += fabsf(gx) * fl;
+            s[3] += fabsf(gy) * fl;
+        }
+        if (a.flags & 4) {
+            const bool allowed = (a.emit.p[(size_t)n * a.emit.bstride + r] > 0.01f) || (a.in0.p[(size_t)n * a.in0.bstride + r] > 0.01f);
+            s[4] += allowed ? 0.f : P[r];
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) s[k] = wave_sum_d(s[k]);
+    if (lane == 0)
+        for (int k = 0; k < 6; ++k) red[wave * 6 + k] = s[k];
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int k = threadIdx.x;
+        atomicAdd(sums + k, red[k] + red[6 + k] + red[12 + k] + red[18 + k]);
+    }
+}
+
+// denominators of the masked means; DP passes the all-reduced global fluid count and its world size so that the
+// plain gradient average over ranks equals the global-batch gradient.
+__device__ __forceinline__ void masked_den(const double* sums, const double* gcnt, int world, float& inv_den, bool& zero) {
+    const double cnt = gcnt ? *gcnt : sums[5];
+    zero = cnt < (double)kLossEps;                       // physics_loss.py:119-121,153-155
+    inv_den = zero ? 0.f : (float)((double)world / (cnt + (double)kLossEps));
+}
+
+// terms: [0] mse [1] divergence [2] gradient [3] emitter [4] total [5] fluid count;  accum[0..4] += wk * terms
+__global__ __launch_bounds__(256) void k_loss_finalize(const double* sums, const double* gcnt, float* terms, float* accum, int B, int H, int W, int flags,
+                                int world, float w_mse, float w_div, float w_grad, float w_emit, float wk) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float inv_den;
+    bool zero;
+    masked_den(sums, gcnt, world, inv_den, zero);
+    const float mse = (float)(sums[0] / ((double)B * 3.0 * H * W));
+    const float dv = (flags & 1) ? (float)(sums[1] * (double)inv_den) : 0.f;
+    const float gr = (flags & 2) ? (float)(sums[2] * (double)inv_den) + (float)(sums[3] * (double)inv_den) : 0.f;
+    const float em = (flags & 4) ? (float)(sums[4] / ((double)B * H * W)) : 0.f;
+    const float total = w_mse * mse + w_div * dv + w_grad * gr + w_emit * em;
+    terms[0] = mse; terms[1] = dv; terms[2] = gr; terms[3] = em; terms[4] = total; terms[5] = (float)sums[5];
+    if (accum) {
+        accum[0] += wk * mse; accum[1] += wk * dv; accum[2] += wk * gr; accum[3] += wk * em; accum[4] += wk * total;
+    }
+}
+
+// masked sign fields S(y,x) whose adjoint stencil gives the gradient
+__device__ __forceinline__ float s_div(const LossArgs& a, const float* P, int n, int y, int x, int HW) {
+    const float fl = fluid_at(a, n, y, x);
+    if (fl == 0.f) return 0.f;
+    return sgn(ddx(P + HW, y, x, a.H, a.W, a.pm, a.stencil, a.dx) + ddy(P + 2 * HW, y, x, a.H, a.W, a.pm, a.stencil, a.dx));
+}
+__device__ __forceinline__ float s_gx(const LossArgs& a, const float* P, const float* T, int n, int y, int x) {
+    const float fl = fluid_at(a, n, y, x);
+    if (fl == 0.f) return 0.f;
+    return sgn(ddx(P, y, x, a.H, a.W, a.pm, a.stencil, a.dx) - ddx(T, y, x, a.H, a.W, a.pm, a.stencil, a.dx));
+}
+__device__ __forceinline__ float s_gy(const LossArgs& a, const float* P, const float* T, int n, int y, int x) {
+    const float fl = fluid_at(a, n, y, x);
+    if (fl == 0.f) return 0.f;
+    return sgn(ddy(P, y, x, a.H, a.W, a.pm, a.stencil, a.dx) - ddy(T, y, x, a.H, a.W, a.pm, a.stencil, a.dx));
+}
+
+// Adjoint of the 1-D difference along one axis: returns sum_{i in plus_pre(j)} S(i) - sum_{i in minus_pre(j)} S(i),
+// where the stencil at i reads index pad_src(i+1) with + and (forward: i | central: pad_src(i-1)) with -.
+template <typename F>
+__device__ __forceinline__ float adj1d(int j, int n, int pm, int stencil, F S) {
+    float acc = 0.f;
+    if (j >= 1) acc += S(j - 1);                                   // i+1 == j
+    if (pad_src(n, n, pm) == j) acc += S(n - 1);                   // right/bottom pad copy
+    if (stencil == FNET_STENCIL_FORWARD) {
+        acc -= S(j);
+    } else {
+        if (j + 1 <= n - 1) acc -= S(j + 1);                       // i-1 == j
+        if (pad_src(-1, n, pm) == j) acc -= S(0);                  // left/top pad copy
+    }
+    return acc;
+}
+
+// dpred[n,c,y,x] = gscale*wk*dL_k/dpred + (gradient arriving from the next rollout step's input)
+__global__ __launch_bounds__(256) void k_loss_grad(LossArgs a, const double* sums, const double* gcnt, const float* dnext, int dnext_bstride,
+                            const float* gscale_ptr, float* dpred, int world, float w_mse, float w_div, float w_grad,
+                            float w_emit, float wk) {
+    const int HW = a.H * a.W, total = a.B * HW;
+    const int idx = blockIdx.x * kThreads + threadIdx.x;
+    if (idx >= total) return;
+    const int n = idx / HW, r = idx - n * HW, y = r / a.W, x = r - y * a.W;
+    const float* P = a.pred + (size_t)n * 3 * HW;
+    const float* T = a.tgt.p + (size_t)n * a.tgt.bstride;
+    float inv_den;
+    bool zero;
+    masked_den(sums, gcnt, world, inv_den, zero);
+    const float gs = (gscale_ptr ? *gscale_ptr : 1.f) * wk;
+    const float cm = gs * w_mse * 2.f / ((float)a.B * 3.f * (float)HW);
+    float g0 = cm * (P[r] - T[r]);
+    float g1 = cm * (P[HW + r] - T[HW + r]);
+    float g2 = cm * (P[2 * HW + r] - T[2 * HW + r]);
+    const float sc = (a.stencil == FNET_STENCIL_FORWARD) ? 1.f / a.dx : 0.5f / a.dx;
+    if ((a.flags & 1) && !zero) {
+        const float c = gs * w_div * inv_den * sc;
+        g1 += c * adj1d(x, a.W, a.pm, a.stencil, [&](int i) { return s_div(a, P, n, y, i, HW); });
+        g2 += c * adj1d(y, a.H, a.pm, a.stencil, [&](int i) { return s_div(a, P, n, i, x, HW); });
+    }
+    if ((a.flags & 2) && !zero) {
+        const float c = gs * w_grad * inv_den * sc;
+        g0 += c * adj1d(x, a.W, a.pm, a.stencil, [&](int i) { return s_gx(a, P, T, n, y, i); });
+        g0 += c * adj1d(y, a.H, a.pm, a.stencil, [&](int i) { return s_gy(a, P, T, n, i, x); });
+    }
+    if (a.flags & 4) {
+        const bool allowed = (a.emit.p[(size_t)n * a.emit.bstride + r] > 0.01f) || (a.in0.p[(size_t)n * a.in0.bstride + r] > 0.01f);
+        if (!allowed) g0 += gs * w_emit / ((float)a.B * (float)HW);
+    }
+    if (dnext) {
+        // next input = cat[pred(3), pred[:,0:1], masks]  (trainer.py:374-379): channels 0 and 3 both hit density
+        const float* D = dnext + (size_t)n * dnext_bstride;
+        g0 += D[r] + D[3 * HW + r];
+        g1 += D[HW + r];
+        g2 += D[2 * HW + r];
+    }
+    float* O = dpred + (size_t)n * 3 * HW;
+    O[r] = g0; O[HW + r] = g1; O[2 * HW + r] = g2;
+}
+
+// ------------------------------------------------------------------ STENCIL free functions
+__global__ __launch_bounds__(256) void k_stencil(const float* f0, const float* f1, float* o0, float* o1, int B, int H, int W, int pm, int stencil,
+                          float dx, float dy, int mode) {
+    const int HW = H * W, total = B * HW;
+    const int idx = blockIdx.x * kThreads + threadIdx.x;
+    if (idx >= total) return;
+    const int n = idx / HW, r = idx - n * HW, y = r / W, x = r - y * W;
+    const float* a = f0 + (size_t)n * HW;
+    if (mode == 0) {  // compute_spatial_gradients
+        o0[idx] = ddx(a, y, x, H, W, pm, stencil, dx);
+        o1[idx] = ddy(a, y, x, H, W, pm, stencil, dy);
+    } else {  // compute_divergence
+        const float* b = f1 + (size_t)n * HW;
+        o0[idx] = ddx(a, y, x, H, W, pm, stencil, dx) + ddy(b, y, x, H, W, pm, stencil, dy);
+    }
+}
+
+// ------------------------------------------------------------------ HEAD (1x1 conv + output activation)
+template <typename T, int MAXO>
+__global__ __launch_bounds__(256) void k_head_fwd(const T* src, const float* Wh, const float* bh, float* z, float* pred, int B, int H, int W, int C,
+                           int ldc, int coff, int Cout, int outact) {
+    extern __shared__ float sw[];  // [Cout][C] + [Cout]
+    for (int i = threadIdx.x; i < Cout * C; i += kThreads) sw[i] = Wh[i];
+    for (int i = threadIdx.x; i < Cout; i += kThreads) sw[Cout * C + i] = bh[i];
+    __syncthreads();
+    const int HW = H * W, total = B * HW;
+    const int idx = blockIdx.x * kThreads + threadIdx.x;
+    if (idx >= total) return;
+    const int n = idx / HW, r = idx - n * HW, y = r / W, x = r - y * W;
+    const T* s = src + (((size_t)n * (H + 2) + y + 1) * (W + 2) + x + 1) * ldc + coff;
+    float acc[MAXO];
+#pragma unroll
+    for (int o = 0; o < MAXO; ++o) acc[o] = o < Cout ? sw[Cout * C + o] : 0.f;
+    for (int c0 = 0; c0 < C; c0 += 8) {
+        Vec8<T> v;
+        v.load(s + c0);
+#pragma unroll
+        for (int o = 0; o < MAXO; ++o)
+            if (o < Cout) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc[o] += v.v[k] * sw[o * C + c0 + k];
+            }
+    }
+#pragma unroll
+    for (int o = 0; o < MAXO; ++o)
+        if (o < Cout) {
+            const float zz = acc[o];
+            float pv;
+            if (outact == FNET_OUT_SIGMOID_TANH) pv = (o == 0) ? 1.f / (1.f + __expf(-zz)) : tanhf(zz);
+            else pv = (o == 0) ? fminf(fmaxf(zz, 0.f), 1.f) : fminf(fmaxf(zz, -1.f), 1.f);
+            const size_t oi = ((size_t)n * Cout + o) * HW + r;
+            z[oi] = zz;
+            pred[oi] = pv;
+        }
+}
+
+// backward: dz = dpred * gate; d_act[c] = sum_o Wh[o][c] dz[o]; dWh[o][c] += sum dz[o] act[c]; dbh[o] += sum dz[o]
+template <typename T, int MAXO, int MAXC>
+__global__ __launch_bounds__(256) void k_head_bwd(const float* dpred, const float* z, const float* pred, const T* act, const float* Wh, T* dact,
+                           float* dWh, float* dbh, int B, int H, int W, int C, int ldc, int coff, int ldc_d, int coff_d, int Cout,
+                           int outact) {
+    extern __shared__ float sw[];  // [Cout][C] weights, then [4 waves][Cout*C + Cout] reduction scratch
+    for (int i = threadIdx.x; i < Cout * C; i += kThreads) sw[i] = Wh[i];
+    __syncthreads();
+    float* red = sw + Cout * C;
+    const int HW = H * W, total = B * HW;
+    float gw[MAXO][MAXC];
+    float gb[MAXO];
+#pragma unroll
+    for (int o = 0; o < MAXO; ++o) {
+        gb[o] = 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) gw[o][c] = 0.f;
+    }
+    for (int idx = blockIdx.x * kThreads + threadIdx.x; idx < total; idx += gridDim.x * kThreads) {
+        const int n = idx / HW, r = idx - n * HW, y = r / W, x = r - y * W;
+        float dz[MAXO];
+#pragma unroll
+        for (int o = 0; o < MAXO; ++o) {
+            dz[o] = 0.f;
+            if (o < Cout) {
+                const size_t oi = ((size_t)n * Cout + o) * HW + r;
+                const float g = dpred[oi], zz = z[oi], pv = pred[oi];
+                if (outact == FNET_OUT_SIGMOID_TANH) dz[o] = (o == 0) ? g * pv * (1.f - pv) : g * (1.f - pv * pv);
+                else {
+                    const float lo = (o == 0) ? 0.f : -1.f;
+                    dz[o] = (zz >= lo && zz <= 1.f) ? g : 0.f;       // torch.clamp backward: inclusive bounds
+                }
+                gb[o] += dz[o];
+            }
+        }
+        const size_t pix = ((size_t)n * (H + 2) + y + 1) * (W + 2) + x + 1;
+#pragma unroll
+        for (int cg = 0; cg < MAXC / 8; ++cg) {
+            if (cg * 8 < C) {
+                Vec8<T> v, d;
+                v.load(act + pix * ldc + coff + cg * 8);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int o = 0; o < MAXO; ++o)
+                        if (o < Cout) {
+                            acc += sw[o * C + cg * 8 + k] * dz[o];
+                            gw[o][cg * 8 + k] += dz[o] * v.v[k];
+                        }
+                    d.v[k] = acc;
+                }
+                d.store(dact + pix * ldc_d + coff_d + cg * 8);
+            }
+        }
+    }
+    // block reduction of gw/gb -> atomics
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nred = Cout * C + Cout;
+#pragma unroll
+    for (int o = 0; o < MAXO; ++o) {
+        if (o < Cout) {
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c)
+                if (c < C) {
+                    const float s = wave_sum(gw[o][c]);
+                    if (lane == 0) red[wave * nred + o * C + c] = s;
+                }
+            const float s = wave_sum(gb[o]);
+            if (lane == 0) red[wave * nred + Cout * C + o] = s;
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nred; i += kThreads) {
+        const float s = red[i] + red[nred + i] + red[2 * nred + i] + red[3 * nred + i];
+        if (i < Cout * C) atomicAdd(dWh + i, s);
+        else atomicAdd(dbh + (i - Cout * C), s);
+    }
+}
+
+inline LossArgs make_loss_args(const FnetOp& op) {
+    LossArgs a;
+    a.pred = (const float*)op.p[0];
+    a.tgt = {(const float*)op.p[1], op.i[3]};
+    a.in0 = {(const float*)op.p[2], op.i[4]};
+    a.emit = {(const float*)op.p[3], op.i[5]};
+    a.coll = {(const float*)op.p[4], op.i[6]};
+    a.B = op.i[0]; a.H = op.i[1]; a.W = op.i[2];
+    a.pm = op.i[7]; a.stencil = op.i[8]; a.flags = op.i[9];
+    a.dx = op.f[0];
+    return a;
+}
+inline bool loss_args_ok(const FnetOp& op) {
+    const int B = op.i[0], H = op.i[1], W = op.i[2];
+    if (!(B > 0 && H >= 2 && W >= 2)) return false;
+    if ((long long)B * H * W >= (1ll << 31)) return false;
+    for (int k = 0; k < 5; ++k) if (!op.p[k]) return false;
+    if (op.i[3] < 3 * H * W || op.i[4] < H * W || op.i[5] < H * W || op.i[6] < H * W) return false;
+    if (op.i[7] < 0 || op.i[7] > 3 || op.i[8] < 0 || op.i[8] > 1) return false;
+    if (!(op.f[0] > 0.f)) return false;
+    return true;
+}
+
+}  // namespace
+
+// LOSS_REDUCE  i: 0 B,1 H,2 W,3 tgt bstride,4 in0 bstride,5 emit bstride,6 coll bstride,7 pm,8 stencil,9 flags; f: 0 dx
+//              p: 0 pred [B,3,H,W],1 target,2 in0 (density_t plane),3 emitter,4 collider,5 sums double[8] (zeroed by the caller)
+int fnet_op_loss_reduce(const FnetOp& op, hipStream_t st) {
+    FNET_CHECK_ARG(loss_args_ok(op) && op.p[5]);
+    const LossArgs a = make_loss_args(op);
+    int blocks = (a.B * a.H * a.W + kThreads * 4 - 1) / (kThreads * 4);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_loss_reduce, dim3(blocks), dim3(kThreads), 0, st, a, (double*)op.p[5]);
+    FNET_LAUNCH_CHECK();
+    return FNET_OK;
+}
+
+// LOSS_FINALIZE  i: 0 B,1 H,2 W,3 flags,4 world; f: 0 w_mse,1 w_div,2 w_grad,3 w_emit,4 wk
+//                p: 0 sums,1 global fluid count double*|0,2 terms float[8],3 accum float[8]|0
+int fnet_op_loss_finalize(const FnetOp& op, hipStream_t st) {
+    FNET_CHECK_ARG(op.i[0] > 0 && op.i[1] > 0 && op.i[2] > 0 && op.i[4] >= 1 && op.p[0] && op.p[2]);
+    hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(64), 0, st, (const double*)op.p[0], (const double*)op.p[1], (float*)op.p[2],
+                       (float*)op.p[3], op.i[0], op.i[1], op.i[2], op.i[3], op.i[4], op.f[0], op.f[1], op.f[2], op.f[3], op.f[4]);
+    FNET_LAUNCH_CHECK();
+    return FNET_OK;
+}
+
+// LOSS_GRAD  i: 0..9 as LOSS_REDUCE,10 world,11 dnext bstride; f: 0 dx,1 w_mse,2 w_div,3 w_grad,4 w_emit,5 wk
+//            p: 0..4 as LOSS_REDUCE,5 sums,6 global count|0,7 dnext [B,>=4,H,W]|0,8 gscale float*|0,9 dpred out [B,3,H,W]
+int fnet_op_loss_grad(const FnetOp& op, hipStream_t st) {
+    FNET_CHECK_ARG(loss_args_ok(op) && op.p[5] && op.p[9] && op.i[10] >= 1);
+    FNET_CHECK_ARG(op.p[7] == 0 || op.i[11] >= 4 * op.i[1] * op.i[2]);
+    const LossArgs a = make_loss_args(op);
+    const int total = a.B * a.H * a.W;
+    hipLaunchKernelGGL(k_loss_grad, dim3((total + kThreads - 1) / kThreads), dim3(kThreads), 0, st, a, (const double*)op.p[5],
+                       (const double*)op.p[6], (const float*)op.p[7], op.i[11], (const float*)op.p[8], (float*)op.p[9], op.i[10],
+                       op.f[1], op.f[2], op.f[3], op.f[4], op.f[5]);
+    FNET_LAUNCH_CHECK();
+    return FNET_OK;
+}
+
+// STENCIL  i: 0 B,1 H,2 W,3 pm,4 stencil,5 mode (0 gradients,1 divergence); f: 0 dx,1 dy; p: 0 f0,1 f1|0,2 out0,3 out1|0
+int fnet_op_stencil(const FnetOp& op, hipStream_t st) {
+    const int B = op.i[0], H = op.i[1], W = op.i[2];
+    FNET_CHECK_ARG(B > 0 && H >= 1 && W >= 1 && (long long)B * H * W < (1ll << 31));
+    FNET_CHECK_ARG(op.i[3] >= 0 && op.i[3] <= 3 && op.i[4] >= 0 && op.i[4] <= 1 && (op.i[5] == 0 || op.i[5] == 1));
+    FNET_CHECK_ARG(op.i[3] != FNET_PAD_REFLECT || (H >= 2 && W >= 2));
+    FNET_CHECK_ARG(op.p[0] && op.p[2] && (op.i[5] == 0 ? op.p[3] != 0 : op.p[1] != 0));
+    FNET_CHECK_ARG(op.f[0] != 0.f && op.f[1] != 0.f);
+    const int total = B * H * W;
+    hipLaunchKernelGGL(k_stencil, dim3((total + kThreads - 1) / kThreads), dim3(kThreads), 0, st, (const float*)op.p[0],
+                       (const float*)op.p[1], (float*)op.p[2], (float*)op.p[3], B, H, W, op.i[3], op.i[4], op.f[0], op.f[1], op.i[5]);
+    FNET_LAUNCH_CHECK();
+    return FNET_OK;
+}
+
+// HEAD_FWD  i: 0 B,1 H,2 W,3 C,4 ldc,5 coff,6 Cout,7 outact; p: 0 src (P),1 Wh fp32 [Cout][C],2 bh,3 z [B,Cout,H,W],4 pred
+int fnet_op_head_fwd(const FnetOp& op, hipStream_t st) {
+    const int B = op.i[0], H = op.i[1], W = op.i[2], C = op.i[3], Cout = op.i[6];
+    FNET_CHECK_ARG(B > 0 && H >= 1 && W >= 1 && C % 8 == 0 && C > 0 && C <= 1024 && Cout >= 1 && Cout <= 4);
+    FNET_CHECK_ARG(op.i[4] % 8 == 0 && op.i[5] % 8 == 0 && op.i[5] + C <= op.i[4]);
+    FNET_CHECK_ARG(op.p[0] && op.p[1] && op.p[2] && op.p[3] && op.p[4] && (op.i[7] == 0 || op.i[7] == 1));
+    const int total = B * H * W;
+    const size_t lds = (size_t)(Cout * C + Cout) * sizeof(float);
+    DISPATCH_T(op.dtype, hipLaunchKernelGGL((k_head_fwd<T, 4>), dim3((total + kThreads - 1) / kThreads), dim3(kThreads), lds, st,
+                                            (const T*)op.p[0], (const float*)op.p[1], (const float*)op.p[2], (float*)op.p[3],
+                                            (float*)op.p[4], B, H, W, C, op.i[4], op.i[5], Cout, op.i[7]));
+    FNET_LAUNCH_CHECK();
+    return FNET_OK;
+}
+
+// HEAD_BWD  i: 0 B,1 H,2 W,3 C,4 ldc,5 coff,6 ldc_d,7 coff_d,8 Cout,9 outact
+//           p: 0 dpred,1 z,2 pred,3 act (P),4 Wh,5 dact out (P interior),6 dWh (+=),7 dbh (+=)
+int fnet_op_head_bwd(const FnetOp& op, hipStream_t st) {
+    const int B = op.i[0], H = op.i[1], W = op.i[2], C = op.i[3], Cout = op.i[8];
+    FNET_CHECK_ARG(B > 0 && H >= 1 && W >= 1 && C % 8 == 0 && C > 0 && C <= 64 && Cout >= 1 && Cout <= 4);
+    FNET_CHECK_ARG(op.i[4] % 8 == 0 && op.i[5] % 8 == 0 && op.i[6] % 8 == 0 && op.i[7] % 8 == 0);
+    for (int k = 0; k < 8; ++k) FNET_CHECK_ARG(op.p[k] != 0);
+    const int total = B * H * W;
+    int blocks = (total + kThreads * 8 - 1) / (kThreads * 8);
+    if (blocks > 1024) blocks = 1024;
+    const size_t lds = (size_t)(Cout * C + 4 * (Cout * C + Cout)) * sizeof(float);
+#define HEAD_BWD_LAUNCH(MAXC)                                                                                              \
+    DISPATCH_T(op.dtype, hipLaunchKernelGGL((k_head_bwd<T, 4, MAXC>), dim3(blocks), dim3(kThreads), lds, st,              \
+                                            (const float*)op.p[0], (const float*)op.p[1], (const float*)op.p[2],           \
+                                            (const T*)op.p[3], (const float*)op.p[4], (T*)op.p[5], (float*)op.p[6],        \
+                                            (float*)op.p[7], B, H, W, C, op.i[4], op.i[5], op.i[6], op.i[7], Cout, op.i[9]))
+    if (C <= 8) { HEAD_BWD_LAUNCH(8); }
+    else if (C <= 16) { HEAD_BWD_LAUNCH(16); }
+    else if (C <= 32) { HEAD_BWD_LAUNCH(32); }
+    else { HEAD_BWD_LAUNCH(64); }
+#undef HEAD_BWD_LAUNCH
+    FNET_LAUNCH_CHECK();
+    return FNET_OK;
+}
+
+extern "C" int fnet_spatial_gradients(const float* field, float* grad_x, float* grad_y, int32_t B, int32_t H, int32_t W, float dx,
+                                      float dy, int32_t padding_mode, int32_t stencil_mode, void* stream) {
+    FnetOp op = {};
+    op.op = FNET_OP_STENCIL;
+    op.i[0] = B; op.i[1] = H; op.i[2] = W; op.i[3] = padding_mode; op.i[4] = stencil_mode; op.i[5] = 0;
+    op.f[0] = dx; op.f[1] = dy;
+    op.p[0] = (uint64_t)field; op.p[2] = (uint64_t)grad_x; op.p[3] = (uint64_t)grad_y;
+    return fnet_op_stencil(op, (hipStream_t)stream);
+}
+extern "C" int fnet_divergence(const float* velx, const float* vely, float* div, int32_t B, int32_t H, int32_t W, float dx, float dy,
+                               int32_t padding_mode, int32_t stencil_mode, void* stream) {
+    FnetOp op = {};
+    op.op = FNET_OP_STENCIL;
+    op.i[0] = B; op.i[1] = H; op.i[2] = W; op.i[3] = padding_mode; op.i[4] = stencil_mode; op.i[5] = 1;
+    op.f[0] = dx; op.f[1] = dy;
+    op.p[0] = (uint64_t)velx; op.p[1] = (uint64_t)vely; op.p[2] = (uint64_t)div;
+    return fnet_op_stencil(op, (hipStream_t)stream);
+}

@@ -1,0 +1,116 @@
+// Weight re-layout (OIHW fp32 master <-> [tap][Cout][Cin] kernel layout), global grad-norm, fused clip + Adam.
+// Replaces clip_grad_norm_ + torch.optim.Adam.step (ml/training/trainer.py:52,192-195).
+#include "fnet_common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+// Wf[t][co][ci] = W[co][ci][t]            (ci < Cin, else 0)        forward conv, K dim = Cin_pad
+// Wd[t][ci][co] = W[co][ci][8-t]          (ci < Cin, else 0)        dgrad as a conv: rows = Cout_d (padded Cin), K dim = Cout
+template <typename T>
+__global__ __launch_bounds__(256) void k_prep_weights(const float* W, T* Wf, T* Wd, int Cout, int Cin, int Cin_pad, int Cout_d) {
+    const int idx = blockIdx.x * kThreads + threadIdx.x;
+    const int nf = 9 * Cout * Cin_pad;
+    const int nd = Wd ? 9 * Cout_d * Cout : 0;
+    if (idx < nf) {
+        const int ci = idx % Cin_pad, co = (idx / Cin_pad) % Cout, t = idx / (Cin_pad * Cout);
+        st1<T>(Wf + idx, ci < Cin ? W[((size_t)co * Cin + ci) * 9 + t] : 0.f);
+    } else if (idx < nf + nd) {
+        const int j = idx - nf;
+        const int co = j % Cout, ci = (j / Cout) % Cout_d, t = j / (Cout * Cout_d);
+        st1<T>(Wd + j, ci < Cin ? W[((size_t)co * Cin + ci) * 9 + (8 - t)] : 0.f);
+    }
+}
+
+// dW[co][ci][t] (+)= dWk[t][co][ci]
+__global__ __launch_bounds__(256) void k_unprep_wgrad(const float* dWk, float* dW, int Cout, int Cin, int Cin_w, int accumulate) {
+    const int idx = blockIdx.x * kThreads + threadIdx.x;
+    if (idx >= Cout * Cin * 9) return;
+    const int t = idx % 9, ci = (idx / 9) % Cin, co = idx / (9 * Cin);
+    const float v = dWk[((size_t)t * Cout + co) * Cin_w + ci];
+    dW[idx] = accumulate ? dW[idx] + v : v;
+}
+
+__global__ __launch_bounds__(256) void k_grad_norm(const float* g, double* out, long long n) {
+    __shared__ double red[4];
+    double s = 0.0;
+    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long long)gridDim.x * kThreads) {
+        const double v = (double)g[i];
+        s += v * v;
+    }
+    s = wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+
+// torch.nn.utils.clip_grad_norm_: coef = min(1, max_norm / (||g|| + 1e-6));  torch.optim.Adam (no amsgrad, wd = 0):
+// m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; p -= (lr / bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
+__global__ __launch_bounds__(256) void k_adam(float* p, const float* g, float* m, float* v, const double* normsq, long long n, float lr,
+                                              float b1, float b2, float eps, float bc1, float bc2_sqrt, float max_norm, float gscale) {
+    float coef = gscale;
+    if (max_norm > 0.f && normsq) {
+        const float total = (float)sqrt(*normsq) * gscale;
+        coef *= fminf(1.f, max_norm / (total + 1e-6f));
+    }
+    const float step = lr / bc1;
+    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long long)gridDim.x * kThreads) {
+        const float gi = g[i] * coef;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] -= step * mi / (sqrtf(vi) / bc2_sqrt + eps);
+    }
+}
+
+}  // namespace
+
+// PREP_WEIGHTS  i: 0 Cout,1 Cin,2 Cin_pad,3 Cout_d; p: 0 W fp32 OIHW,1 Wf [9][Cout][Cin_pad],2 Wd [9][Cout_d][Cout]|0
+int fnet_op_prep_weights(const FnetOp& op, hipStream_t st) {
+    const int Cout = op.i[0], Cin = op.i[1], Cin_pad = op.i[2], Cout_d = op.i[3];
+    FNET_CHECK_ARG(Cout > 0 && Cin > 0 && Cin_pad >= Cin && op.p[0] && op.p[1] && (op.p[2] == 0 || Cout_d >= Cin));
+    const int total = 9 * Cout * Cin_pad + (op.p[2] ? 9 * Cout_d * Cout : 0);
+    DISPATCH_T(op.dtype, hipLaunchKernelGGL(k_prep_weights<T>, dim3((total + kThreads - 1) / kThreads), dim3(kThreads), 0, st,
+                                            (const float*)op.p[0], (T*)op.p[1], (T*)op.p[2], Cout, Cin, Cin_pad, Cout_d));
+    FNET_LAUNCH_CHECK();
+    return FNET_OK;
+}
+
+// UNPREP_WGRAD  i: 0 Cout,1 Cin,2 Cin_w,3 accumulate; p: 0 dWk fp32 [9][Cout][Cin_w],1 dW fp32 OIHW
+int fnet_op_unprep_wgrad(const FnetOp& op, hipStream_t st) {
+    const int Cout = op.i[0], Cin = op.i[1], Cin_w = op.i[2];
+    FNET_CHECK_ARG(Cout > 0 && Cin > 0 && Cin_w >= Cin && op.p[0] && op.p[1]);
+    const int total = 9 * Cout * Cin;
+    hipLaunchKernelGGL(k_unprep_wgrad, dim3((total + kThreads - 1) / kThreads), dim3(kThreads), 0, st, (const float*)op.p[0],
+                       (float*)op.p[1], Cout, Cin, Cin_w, op.i[3]);
+    FNET_LAUNCH_CHECK();
+    return FNET_OK;
+}
+
+// GRAD_NORM  i: 0 n & 0x7fffffff,1 n >> 31; p: 0 grads fp32,1 sum of squares double* (+=; zero it first)
+int fnet_op_grad_norm(const FnetOp& op, hipStream_t st) {
+    const long long n = (long long)op.i[0] + ((long long)op.i[1] << 31);
+    FNET_CHECK_ARG(n > 0 && op.p[0] && op.p[1]);
+    long long blocks = (n + kThreads * 8 - 1) / (kThreads * 8);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_grad_norm, dim3((unsigned)blocks), dim3(kThreads), 0, st, (const float*)op.p[0], (double*)op.p[1], n);
+    FNET_LAUNCH_CHECK();
+    return FNET_OK;
+}
+
+// ADAM  i: 0 n & 0x7fffffff,1 n >> 31; f: 0 lr,1 beta1,2 beta2,3 eps,4 bc1 = 1-beta1^t,5 sqrt(1-beta2^t),6 max_norm (<=0: no clip),7 grad scale
+//       p: 0 params,1 grads,2 exp_avg,3 exp_avg_sq,4 sum of squares double*|0
+int fnet_op_adam(const FnetOp& op, hipStream_t st) {
+    const long long n = (long long)op.i[0] + ((long long)op.i[1] << 31);
+    FNET_CHECK_ARG(n > 0 && op.p[0] && op.p[1] && op.p[2] && op.p[3]);
+    FNET_CHECK_ARG(op.f[4] > 0.f && op.f[5] > 0.f && (op.f[6] <= 0.f || op.p[4] != 0));
+    long long blocks = (n + kThreads * 4 - 1) / (kThreads * 4);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_adam, dim3((unsigned)blocks), dim3(kThreads), 0, st, (float*)op.p[0], (const float*)op.p[1], (float*)op.p[2],
+                       (float*)op.p[3], (const double*)op.p[4], n, op.f[0], op.f[1], op.f[2], op.f[3], op.f[4], op.f[5], op.f[6],
+                       op.f[7]);
+    FNET_LAUNCH_CHECK();
+    return FNET_OK;
+}

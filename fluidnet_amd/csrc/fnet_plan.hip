@@ -1,0 +1,172 @@
+// Plan executor, hipGraph capture/replay, HIP-event timers: the native runtime under the Python host mirror.
+#include <stdio.h>
+
+#include "fnet_common.h"
+
+static int dispatch_op(const FnetOp& op, hipStream_t st) {
+    switch (op.op) {
+        case FNET_OP_NOP: return FNET_OK;
+        case FNET_OP_PACK_INPUT: return fnet_op_pack_input(op, st);
+        case FNET_OP_CONV3X3: return fnet_op_conv3x3(op, st);
+        case FNET_OP_WGRAD: return fnet_op_wgrad(op, st);
+        case FNET_OP_IN_STATS: return fnet_op_in_stats(op, st);
+        case FNET_OP_APPLY: return fnet_op_apply(op, st);
+        case FNET_OP_UPSAMPLE2X: return fnet_op_upsample2x(op, st);
+        case FNET_OP_SUBSAMPLE_BIAS: return fnet_op_subsample_bias(op, st);
+        case FNET_OP_PAD_RING: return fnet_op_pad_ring(op, st);
+        case FNET_OP_HEAD_FWD: return fnet_op_head_fwd(op, st);
+        case FNET_OP_LOSS_REDUCE: return fnet_op_loss_reduce(op, st);
+        case FNET_OP_LOSS_FINALIZE: return fnet_op_loss_finalize(op, st);
+        case FNET_OP_LOSS_GRAD: return fnet_op_loss_grad(op, st);
+        case FNET_OP_HEAD_BWD: return fnet_op_head_bwd(op, st);
+        case FNET_OP_INACT_BWD_REDUCE: return fnet_op_inact_bwd_reduce(op, st);
+        case FNET_OP_INACT_BWD_APPLY: return fnet_op_inact_bwd_apply(op, st);
+        case FNET_OP_AFFINE_GRAD: return fnet_op_affine_grad(op, st);
+        case FNET_OP_FOLD_SUM: return fnet_op_fold_sum(op, st);
+        case FNET_OP_BIAS_GRAD: return fnet_op_bias_grad(op, st);
+        case FNET_OP_ZERO_INSERT: return fnet_op_zero_insert(op, st);
+        case FNET_OP_UPSAMPLE2X_BWD: return fnet_op_upsample2x_bwd(op, st);
+        case FNET_OP_UNPACK_GRAD: return fnet_op_unpack_grad(op, st);
+        case FNET_OP_ZERO: return fnet_op_zero(op, st);
+        case FNET_OP_PREP_WEIGHTS: return fnet_op_prep_weights(op, st);
+        case FNET_OP_GRAD_NORM: return fnet_op_grad_norm(op, st);
+        case FNET_OP_ADAM: return fnet_op_adam(op, st);
+        case FNET_OP_COPY_PLANES: return fnet_op_copy_planes(op, st);
+        case FNET_OP_UNPREP_WGRAD: return fnet_op_unprep_wgrad(op, st);
+        case FNET_OP_STENCIL: return fnet_op_stencil(op, st);
+        default: return FNET_E_BADARG;
+    }
+}
+
+struct FnetGraph {
+    hipGraph_t graph;
+    hipGraphExec_t exec;
+};
+struct FnetTimer {
+    hipEvent_t a, b;
+};
+
+#define HIP_TRY(x)                                \
+    do {                                          \
+        hipError_t e__ = (x);                     \
+        if (e__ != hipSuccess) {                  \
+            g_fnet_last_hip_error = (int)e__;     \
+            return FNET_E_HIP;                    \
+        }                                         \
+    } while (0)
+
+extern "C" {
+
+int fnet_abi_version(void) { return FNET_ABI_VERSION; }
+
+const char* fnet_strerror(int code) {
+    switch (code) {
+        case FNET_OK: return "ok";
+        case FNET_E_BADARG: return "bad argument (shape, alignment or enum) -- nothing was launched for that op";
+        case FNET_E_HIP: return "HIP runtime error (see fnet_last_hip_error)";
+        case FNET_E_UNSUPPORTED: return "unsupported configuration";
+        default: return "unknown error";
+    }
+}
+
+int fnet_last_hip_error(void) { return g_fnet_last_hip_error; }
+
+int fnet_device_info(int32_t out[4]) {
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    out[0] = prop.multiProcessorCount;
+    out[1] = (int32_t)prop.sharedMemPerBlock;
+    out[2] = prop.warpSize;
+    out[3] = prop.major * 100 + prop.minor;
+    return FNET_OK;
+}
+
+int fnet_plan_run(const FnetOp* ops, int32_t n_ops, void* stream, int32_t* failed_index) {
+    if (!ops || n_ops < 0) return FNET_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    for (int32_t k = 0; k < n_ops; ++k) {
+        const int rc = dispatch_op(ops[k], st);
+        if (rc != FNET_OK) {
+            if (failed_index) *failed_index = k;
+            return rc;
+        }
+    }
+    if (failed_index) *failed_index = -1;
+    return FNET_OK;
+}
+
+int fnet_graph_create(const FnetOp* ops, int32_t n_ops, void** graph_out) {
+    if (!ops || n_ops <= 0 || !graph_out) return FNET_E_BADARG;
+    hipStream_t cap;
+    HIP_TRY(hipStreamCreateWithFlags(&cap, hipStreamNonBlocking));
+    hipError_t e = hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal);
+    if (e != hipSuccess) { g_fnet_last_hip_error = (int)e; hipStreamDestroy(cap); return FNET_E_HIP; }
+    int32_t bad = -1;
+    const int rc = fnet_plan_run(ops, n_ops, (void*)cap, &bad);
+    hipGraph_t g = nullptr;
+    e = hipStreamEndCapture(cap, &g);
+    hipStreamDestroy(cap);
+    if (rc != FNET_OK) { if (g) hipGraphDestroy(g); return rc; }
+    if (e != hipSuccess || !g) { g_fnet_last_hip_error = (int)e; return FNET_E_HIP; }
+    hipGraphExec_t ex = nullptr;
+    e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+    if (e != hipSuccess) { g_fnet_last_hip_error = (int)e; hipGraphDestroy(g); return FNET_E_HIP; }
+    FnetGraph* fg = new FnetGraph{g, ex};
+    *graph_out = (void*)fg;
+    return FNET_OK;
+}
+
+int fnet_graph_launch(void* graph, void* stream, int32_t repeat) {
+    if (!graph || repeat < 1) return FNET_E_BADARG;
+    FnetGraph* fg = (FnetGraph*)graph;
+    for (int32_t r = 0; r < repeat; ++r) HIP_TRY(hipGraphLaunch(fg->exec, (hipStream_t)stream));
+    return FNET_OK;
+}
+
+int fnet_graph_destroy(void* graph) {
+    if (!graph) return FNET_E_BADARG;
+    FnetGraph* fg = (FnetGraph*)graph;
+    hipGraphExecDestroy(fg->exec);
+    hipGraphDestroy(fg->graph);
+    delete fg;
+    return FNET_OK;
+}
+
+int fnet_timer_create(void** timer_out) {
+    if (!timer_out) return FNET_E_BADARG;
+    FnetTimer* t = new FnetTimer;
+    hipError_t e = hipEventCreate(&t->a);
+    if (e == hipSuccess) e = hipEventCreate(&t->b);
+    if (e != hipSuccess) { g_fnet_last_hip_error = (int)e; delete t; return FNET_E_HIP; }
+    *timer_out = (void*)t;
+    return FNET_OK;
+}
+int fnet_timer_start(void* timer, void* stream) {
+    if (!timer) return FNET_E_BADARG;
+    HIP_TRY(hipEventRecord(((FnetTimer*)timer)->a, (hipStream_t)stream));
+    return FNET_OK;
+}
+int fnet_timer_stop(void* timer, void* stream) {
+    if (!timer) return FNET_E_BADARG;
+    HIP_TRY(hipEventRecord(((FnetTimer*)timer)->b, (hipStream_t)stream));
+    return FNET_OK;
+}
+int fnet_timer_elapsed_ms(void* timer, float* ms_out) {
+    if (!timer || !ms_out) return FNET_E_BADARG;
+    FnetTimer* t = (FnetTimer*)timer;
+    HIP_TRY(hipEventSynchronize(t->b));
+    HIP_TRY(hipEventElapsedTime(ms_out, t->a, t->b));
+    return FNET_OK;
+}
+int fnet_timer_destroy(void* timer) {
+    if (!timer) return FNET_E_BADARG;
+    FnetTimer* t = (FnetTimer*)timer;
+    hipEventDestroy(t->a);
+    hipEventDestroy(t->b);
+    delete t;
+    return FNET_OK;
+}
+
+}  // extern "C"

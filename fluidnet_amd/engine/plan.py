@@ -1,0 +1,594 @@
+"""Plan builder: turns (UNetConfig, B, H, W, K) into flat op lists for fnet_plan_run.
+
+The builder is tensor-agnostic: it emits OpRec records that reference Buf handles.  `bind()` allocates the
+buffers on a device and lowers the records to the FnetOp array of include/fluidnet_hip.h.  (tests/sim_ops.py
+interprets the very same records on CPU tensors, which is how the graph wiring is checked without a GPU.)
+
+Forward graph = ml/models/unet.py:281-303; backward graph = its hand-derived adjoint;
+rollout loss = ml/training/trainer.py:311-385; optimiser = trainer.py:190-195.
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import runtime as rt
+from .runtime import OPC
+
+
+# ------------------------------------------------------------------------------------------------ handles
+@dataclass(eq=False)
+class Buf:
+    name: str
+    shape: Tuple[int, ...]
+    kind: str                      # 'T' (plan element type), 'f32', 'f64'
+    external: bool = False         # bound by the caller (params, inputs, outputs)
+    tensor: object = None
+    rc: int = 0                    # refcount for pooled temporaries
+
+    @property
+    def numel(self) -> int:
+        return int(np.prod(self.shape))
+
+
+@dataclass(eq=False)
+class Ref:
+    buf: Buf
+    off: int = 0                   # element offset
+
+
+@dataclass(eq=False)
+class PV:
+    """View of channels [coff, coff+C) of a P-tensor buffer [B, H+2, W+2, ldc]."""
+    buf: Buf
+    C: int
+    coff: int = 0
+
+    @property
+    def ldc(self) -> int:
+        return self.buf.shape[3]
+
+    @property
+    def H(self) -> int:
+        return self.buf.shape[1] - 2
+
+    @property
+    def W(self) -> int:
+        return self.buf.shape[2] - 2
+
+    @property
+    def ref(self) -> Ref:
+        return Ref(self.buf, 0)
+
+
+@dataclass(eq=False)
+class GradSrc:
+    """A gradient contribution: a P view, to be read plainly (fold=0) or with the padding ring folded in (fold=1)."""
+    pv: PV
+    fold: int
+
+
+@dataclass(eq=False)
+class OpRec:
+    code: int
+    i: List[int] = field(default_factory=list)
+    f: List[float] = field(default_factory=list)
+    p: List[Optional[Ref]] = field(default_factory=list)
+    dtype: int = 0
+    tag: str = ""
+
+
+@dataclass(eq=False)
+class Unit:
+    """conv3x3 -> InstanceNorm -> activation -> Dropout2d [-> + residual]  (half of a ConvBlock, unet.py:65-69)."""
+    conv: str
+    norm: str
+    xin: PV
+    raw: Buf
+    st: Buf
+    out: PV
+    res: Optional[PV]
+    drop_site: int
+    drop_p: float
+
+
+@dataclass(eq=False)
+class PlainConv:
+    """conv3x3 + bias with no norm/activation: the stem (stride 1) and the stride-2 `down` convs."""
+    conv: str
+    xin: PV
+    out: PV            # padded output at the conv's output resolution
+    stride: int
+
+
+@dataclass(eq=False)
+class Tape:
+    app: int
+    in_p: Buf = None
+    stem: PlainConv = None
+    downs: list = field(default_factory=list)     # per level: dict(block=[u1,u2], res=[u1,u2]|None, down=PlainConv, cat=Buf)
+    mids: list = field(default_factory=list)      # per block: [u1,u2]
+    ups: list = field(default_factory=list)       # per level (forward order): dict(block, res, cat, xlow=PV, C)
+    head_in: PV = None
+    z: Buf = None
+    pred: Buf = None
+
+
+def unet_param_shapes(cfg) -> "OrderedDict[str, Tuple[int, ...]]":
+    """State-dict order/shapes of the trainable tensors (ml/models/unet.py:204-279) for the supported family."""
+    out: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
+
+    def block(prefix, cin, cout):
+        for idx, (ci, co) in enumerate(((cin, cout), (cout, cout)), start=1):
+            out[f"{prefix}.c{idx}.weight"] = (co, ci, 3, 3)
+            if cfg.norm == "none":
+                out[f"{prefix}.c{idx}.bias"] = (co,)
+            else:
+                out[f"{prefix}.n{idx}.weight"] = (co,)
+                out[f"{prefix}.n{idx}.bias"] = (co,)
+
+    out["stem.weight"] = (cfg.base_channels, cfg.in_channels, 3, 3)
+    out["stem.bias"] = (cfg.base_channels,)
+    ch = cfg.base_channels
+    skips = []
+    for L in range(cfg.depth):
+        oc = ch * 2
+        block(f"downs.{L}.block", ch, oc)
+        if cfg.use_residual:
+            block(f"downs.{L}.res.b", oc, oc)
+        dk = f"downs.{L}.down" if cfg.downsample == "stride" else f"downs.{L}.down.1"
+        out[f"{dk}.weight"] = (oc, oc, 3, 3)
+        out[f"{dk}.bias"] = (oc,)
+        skips.append(oc)
+        ch = oc
+    for j in range(max(0, cfg.bottleneck_blocks)):
+        block(f"mid.{j}.b", ch, ch)
+    for i, L in enumerate(reversed(range(cfg.depth))):
+        sc = skips[L]
+        oc = sc // 2
+        if cfg.upsample == "transpose":
+            out[f"ups.{i}.up.weight"] = (ch, ch, 2, 2)
+            out[f"ups.{i}.up.bias"] = (ch,)
+        block(f"ups.{i}.block", ch + sc, oc)
+        if cfg.use_residual:
+            block(f"ups.{i}.res.b", oc, oc)
+        ch = oc
+    out["head.weight"] = (cfg.out_channels, ch, 1, 1)
+    out["head.bias"] = (cfg.out_channels,)
+    return out
+
+
+def check_supported(cfg, H: int, W: int) -> None:
+    """The HIP engine covers the UNet_medium family; anything else fails loudly (no fallback)."""
+    bad = []
+    if cfg.norm != "instance":
+        bad.append(f"norm={cfg.norm!r} (only 'instance')")
+    if cfg.downsample != "stride":
+        bad.append(f"downsample={cfg.downsample!r} (only 'stride')")
+    if cfg.upsample not in ("bilinear", "nearest"):
+        bad.append(f"upsample={cfg.upsample!r} (only 'bilinear'/'nearest')")
+    if cfg.in_channels != 6:
+        bad.append(f"in_channels={cfg.in_channels} (only 6)")
+    if not (1 <= cfg.out_channels <= 4):
+        bad.append(f"out_channels={cfg.out_channels}")
+    if cfg.base_channels % 8 != 0:
+        bad.append(f"base_channels={cfg.base_channels} (multiple of 8)")
+    if cfg.base_channels > 64:
+        bad.append(f"base_channels={cfg.base_channels} (head kernels cover <= 64)")
+    if cfg.depth < 1:
+        raise ValueError("depth must be >= 1")
+    div = 2 ** cfg.depth
+    if H % div or W % div or H // div < 2 or W // div < 2:
+        bad.append(f"grid {H}x{W} must be divisible by 2^depth with >= 2 cells left")
+    if cfg.padding_mode not in rt.PAD or cfg.act not in rt.ACT or cfg.output_activation not in rt.OUTACT:
+        bad.append("unknown padding_mode/act/output_activation")
+    if bad:
+        raise NotImplementedError("fluidnet_amd HIP engine does not support: " + "; ".join(bad))
+
+
+class PlanBuilder:
+    def __init__(self, cfg, B: int, H: int, W: int, dtype: str = "bf16", conv_impl: str = "auto", training: bool = True,
+                 seed: int = 0):
+        check_supported(cfg, H, W)
+        assert dtype in ("fp32", "bf16")
+        self.cfg, self.B, self.H, self.W = cfg, B, H, W
+        self.dtype = rt.BF16 if dtype == "bf16" else rt.F32
+        self.dtype_name = dtype
+        self.conv_impl = conv_impl
+        self.training = training
+        self.seed = seed & 0x7FFFFFFF
+        self.pm = rt.PAD[cfg.padding_mode]
+        self.act = rt.ACT[cfg.act]
+        self.bufs: List[Buf] = []
+        self.pool: Dict[Tuple, List[Buf]] = {}
+        self.shapes = unet_param_shapes(cfg)
+        self.offsets: "OrderedDict[str, int]" = OrderedDict()
+        off = 0
+        for k, s in self.shapes.items():
+            self.offsets[k] = off
+            off += int(np.prod(s))
+            off = (off + 7) // 8 * 8           # keep every tensor 32-B aligned inside the flat buffers
+        self.n_params_padded = off
+        self.params = self.new_buf("params_flat", (off,), "f32", external=True)
+        self.grads = self.new_buf("grads_flat", (off,), "f32", external=True)
+        self.convs: "OrderedDict[str, dict]" = OrderedDict()
+        for k, s in self.shapes.items():
+            if len(s) == 4 and s[2] == 3:
+                name = k[: -len(".weight")]
+                co, ci = s[0], s[1]
+                cip = 16 if name == "stem" else ci       # only the 6-channel stem input is padded (to one MFMA k-step)
+                self.convs[name] = dict(
+                    Cout=co, Cin=ci, Cin_pad=cip, Cout_d=cip,
+                    Wf=self.new_buf(f"Wf/{name}", (9, co, cip), "T"),
+                    Wd=self.new_buf(f"Wd/{name}", (9, cip, co), "T"),
+                    dWk=self.new_buf(f"dWk/{name}", (9, co, cip), "f32"))
+
+    # -------------------------------------------------------------------------------------------- buffers
+    def new_buf(self, name, shape, kind, external=False) -> Buf:
+        b = Buf(name, tuple(int(s) for s in shape), kind, external)
+        self.bufs.append(b)
+        return b
+
+    def pbuf(self, name, H, W, C) -> Buf:
+        return self.new_buf(name, (self.B, H + 2, W + 2, C), "T")
+
+    def tmp(self, H, W, C) -> Buf:
+        key = (H, W, C)
+        lst = self.pool.setdefault(key, [])
+        b = lst.pop() if lst else self.pbuf(f"tmp/{H}x{W}x{C}/{sum(1 for x in self.bufs if x.name.startswith('tmp/'))}", H, W, C)
+        b.rc = 1
+        return b
+
+    def retain(self, b: Buf) -> None:
+        if b.name.startswith("tmp/"):
+            b.rc += 1
+
+    def release(self, b: Buf) -> None:
+        if not b.name.startswith("tmp/"):
+            return
+        b.rc -= 1
+        assert b.rc >= 0, b.name
+        if b.rc == 0:
+            self.pool[(b.shape[1] - 2, b.shape[2] - 2, b.shape[3])].append(b)
+
+    def pref(self, name: str) -> Ref:
+        return Ref(self.params, self.offsets[name])
+
+    def gref(self, name: str) -> Ref:
+        return Ref(self.grads, self.offsets[name])
+
+    def impl_for(self, cin: int, cout: int) -> int:
+        if self.conv_impl == "ref" or self.dtype != rt.BF16:
+            return rt.CONV_REF
+        ok = cin % 16 == 0 and cout % 8 == 0
+        if self.conv_impl == "mfma" and not ok:
+            raise NotImplementedError(f"MFMA conv needs Cin%16==0 and Cout%8==0 (got {cin}->{cout})")
+        return rt.CONV_MFMA if ok else rt.CONV_REF
+
+    # -------------------------------------------------------------------------------------------- op emitters
+    def op(self, ops, code, i, f=(), p=(), tag="") -> None:
+        ops.append(OpRec(OPC[code], [int(v) for v in i], [float(v) for v in f], list(p), self.dtype, tag))
+
+    def e_pack(self, ops, planes: Sequence[Tuple[Ref, int]], dst: Buf):
+        assert len(planes) == 6
+        self.op(ops, "PACK_INPUT", [self.B, dst.shape[1] - 2, dst.shape[2] - 2, dst.shape[3], self.pm] + [s for _, s in planes],
+                p=[r for r, _ in planes] + [Ref(dst)], tag=dst.name)
+
+    def e_conv(self, ops, src: PV, wbuf: Buf, bias: Optional[Ref], dst: PV, cin: int, cout: int, tag=""):
+        npix = self.B * (src.H + 2) * (src.W + 2)
+        assert (dst.H, dst.W) == (src.H, src.W) and src.C == cin and dst.C == cout, (tag, src.C, cin, dst.C, cout)
+        self.op(ops, "CONV3X3", [npix, src.W + 2, cin, src.ldc, src.coff, cout, dst.ldc, dst.coff, self.impl_for(cin, cout)],
+                p=[src.ref, Ref(wbuf), bias, dst.ref], tag=tag)
+
+    def e_wgrad(self, ops, src: PV, dout: PV, conv: str):
+        c = self.convs[conv]
+        npix = self.B * (src.H + 2) * (src.W + 2)
+        assert src.C == c["Cin_pad"] and dout.C == c["Cout"], (conv, src.C, dout.C)
+        self.op(ops, "WGRAD", [npix, src.W + 2, src.C, src.ldc, src.coff, dout.C, dout.ldc, dout.coff,
+                               self.impl_for(src.C, dout.C), c["Cin_pad"]],
+                p=[src.ref, dout.ref, Ref(c["dWk"])], tag=conv)
+
+    def e_stats(self, ops, raw: PV, st: Buf):
+        self.op(ops, "IN_STATS", [self.B, raw.H, raw.W, raw.C, raw.ldc, raw.coff], f=[1e-5], p=[raw.ref, Ref(st)])
+
+    def e_apply(self, ops, u: Unit):
+        raw = PV(u.raw, u.out.C)
+        res = u.res
+        self.op(ops, "APPLY", [self.B, raw.H, raw.W, raw.C, raw.ldc, raw.coff, res.ldc if res else 8, res.coff if res else 0,
+                               u.out.ldc, u.out.coff, self.act, self.pm, u.drop_site, self.seed],
+                f=[u.drop_p],
+                p=[raw.ref, Ref(u.st), self.pref(u.norm + ".weight"), self.pref(u.norm + ".bias"), res.ref if res else None, u.out.ref],
+                tag=u.conv)
+
+    # -------------------------------------------------------------------------------------------- forward
+    def _unit(self, ops, tape_name: str, conv: str, norm: str, xin: PV, cout: int, out: Optional[PV], res: Optional[PV],
+              drop_site: int, drop_p: float) -> Unit:
+        H, W = xin.H, xin.W
+        c = self.convs[conv]
+        raw = self.pbuf(f"{tape_name}/{conv}/raw", H, W, cout)
+        st = self.new_buf(f"{tape_name}/{conv}/stats", (self.B, cout, 2), "f32")
+        if out is None:
+            out = PV(self.pbuf(f"{tape_name}/{conv}/act", H, W, cout), cout)
+        u = Unit(conv, norm, xin, raw, st, out, res, drop_site, drop_p)
+        self.e_conv(ops, xin, c["Wf"], None, PV(raw, cout), c["Cin_pad"], cout, tag=conv)
+        self.e_stats(ops, PV(raw, cout), st)
+        self.e_apply(ops, u)
+        return u
+
+    def _conv_block(self, ops, tn, key, xin: PV, cout, out: Optional[PV], residual: bool, site: int) -> List[Unit]:
+        p = self.cfg.dropout if self.training else 0.0
+        u1 = self._unit(ops, tn, f"{key}.c1", f"{key}.n1", xin, cout, None, None, site, p)
+        u2 = self._unit(ops, tn, f"{key}.c2", f"{key}.n2", u1.out, cout, out, xin if residual else None, 0, 0.0)
+        return [u1, u2]
+
+    def emit_forward(self, ops, app: int, planes: Sequence[Tuple[Ref, int]], pred: Optional[Buf] = None) -> Tape:
+        cfg, B, H, W = self.cfg, self.B, self.H, self.W
+        tn = f"tape{app}"
+        t = Tape(app)
+        site = app * 64
+        t.in_p = self.pbuf(f"{tn}/in_p", H, W, 16)
+        self.e_pack(ops, planes, t.in_p)
+        base = cfg.base_channels
+        s_p = self.pbuf(f"{tn}/stem", H, W, base)
+        t.stem = PlainConv("stem", PV(t.in_p, 16), PV(s_p, base), 1)
+        self.e_conv(ops, t.stem.xin, self.convs["stem"]["Wf"], self.pref("stem.bias"), t.stem.out, 16, base, tag="stem")
+        self.op(ops, "PAD_RING", [B, H, W, base, base, 0, self.pm], p=[Ref(s_p)])
+        x = t.stem.out
+        h, w, ch = H, W, base
+        for L in range(cfg.depth):
+            C = ch * 2
+            cat = self.pbuf(f"{tn}/cat{L}", h, w, 2 * C)
+            skip = PV(cat, C, C)
+            d = dict(cat=cat, C=C)
+            if cfg.use_residual:
+                d["block"] = self._conv_block(ops, tn, f"downs.{L}.block", x, C, None, False, site); site += 1
+                d["res"] = self._conv_block(ops, tn, f"downs.{L}.res.b", d["block"][1].out, C, skip, True, site); site += 1
+            else:
+                d["block"] = self._conv_block(ops, tn, f"downs.{L}.block", x, C, skip, False, site); site += 1
+                d["res"] = None
+            full = self.tmp(h, w, C)
+            name = f"downs.{L}.down"
+            self.e_conv(ops, skip, self.convs[name]["Wf"], None, PV(full, C), C, C, tag=name)
+            dn = self.pbuf(f"{tn}/dn{L}", h // 2, w // 2, C)
+            self.op(ops, "SUBSAMPLE_BIAS", [B, h, w, C, C, 0, C, 0, self.pm], p=[Ref(full), self.pref(name + ".bias"), Ref(dn)], tag=name)
+            self.release(full)
+            d["down"] = PlainConv(name, skip, PV(dn, C), 2)
+            t.downs.append(d)
+            x = d["down"].out
+            h, w, ch = h // 2, w // 2, C
+        for j in range(max(0, cfg.bottleneck_blocks)):
+            t.mids.append(self._conv_block(ops, tn, f"mid.{j}.b", x, ch, None, True, site)); site += 1
+            x = t.mids[-1][1].out
+        for i, L in enumerate(reversed(range(cfg.depth))):
+            d = t.downs[L]
+            C = d["C"]
+            assert ch == C
+            h, w = h * 2, w * 2
+            self.op(ops, "UPSAMPLE2X", [B, h // 2, w // 2, C, x.ldc, x.coff, 2 * C, 0, 1 if cfg.upsample == "bilinear" else 0, self.pm],
+                    p=[x.ref, Ref(d["cat"])], tag=f"ups.{i}.up")
+            u = dict(cat=d["cat"], C=C, xlow=x)
+            u["block"] = self._conv_block(ops, tn, f"ups.{i}.block", PV(d["cat"], 2 * C, 0), C // 2, None, False, site); site += 1
+            x = u["block"][1].out
+            if cfg.use_residual:
+                u["res"] = self._conv_block(ops, tn, f"ups.{i}.res.b", x, C // 2, None, True, site); site += 1
+                x = u["res"][1].out
+            else:
+                u["res"] = None
+            t.ups.append(u)
+            ch = C // 2
+        t.head_in = x
+        co = cfg.out_channels
+        t.z = self.new_buf(f"{tn}/z", (B, co, H, W), "f32")
+        t.pred = pred if pred is not None else self.new_buf(f"{tn}/pred", (B, co, H, W), "f32")
+        self.op(ops, "HEAD_FWD", [B, H, W, x.C, x.ldc, x.coff, co, rt.OUTACT[cfg.output_activation]],
+                p=[x.ref, self.pref("head.weight"), self.pref("head.bias"), Ref(t.z), Ref(t.pred)], tag="head")
+        return t
+
+    # -------------------------------------------------------------------------------------------- backward
+    def _unit_bwd(self, ops, u: Unit, srcs: List[GradSrc], need_dx: bool = True) -> Tuple[Optional[GradSrc], Buf]:
+        """Backward of one unit.  Consumes (releases) the temporaries behind `srcs`.  Returns (gradient wrt the unit's
+        input as a folded source or None, the materialised total gradient G wrt the unit's output (caller releases))."""
+        assert 1 <= len(srcs) <= 2
+        B, H, W, C = self.B, u.out.H, u.out.W, u.out.C
+        G = self.tmp(H, W, C)
+        S = self.new_buf(f"S/{u.conv}/{len(self.bufs)}", (B, C, 2), "f32")
+        g1 = srcs[0]
+        g2 = srcs[1] if len(srcs) > 1 else None
+        self.op(ops, "INACT_BWD_REDUCE",
+                [B, H, W, C, g1.pv.ldc, g1.pv.coff, g2.pv.ldc if g2 else 8, g2.pv.coff if g2 else 0, C, 0, C, 0,
+                 g1.fold, g2.fold if g2 else 0, self.act, self.pm, u.drop_site, self.seed],
+                f=[u.drop_p],
+                p=[g1.pv.ref, g2.pv.ref if g2 else None, Ref(u.raw), Ref(u.st), self.pref(u.norm + ".weight"),
+                   self.pref(u.norm + ".bias"), Ref(G), Ref(S)], tag=u.conv)
+        for s in srcs:
+            self.release(s.pv.buf)
+        draw = self.tmp(H, W, C)
+        self.op(ops, "INACT_BWD_APPLY", [B, H, W, C, C, 0, C, 0, C, 0, self.act, u.drop_site, self.seed], f=[u.drop_p],
+                p=[Ref(G), Ref(u.raw), Ref(u.st), self.pref(u.norm + ".weight"), self.pref(u.norm + ".bias"), Ref(S), Ref(draw)],
+                tag=u.conv)
+        self.op(ops, "AFFINE_GRAD", [B, C], p=[Ref(S), self.gref(u.norm + ".weight"), self.gref(u.norm + ".bias")], tag=u.norm)
+        self.e_wgrad(ops, u.xin, PV(draw, C), u.conv)
+        dx = None
+        if need_dx:
+            cin = u.xin.C
+            dpad = self.tmp(H, W, cin)
+            self.e_conv(ops, PV(draw, C), self.convs[u.conv]["Wd"], None, PV(dpad, cin), C, cin, tag=u.conv + "/dgrad")
+            dx = GradSrc(PV(dpad, cin), 1)
+        self.release(draw)
+        return dx, G
+
+    def _block_bwd(self, ops, units: List[Unit], srcs: List[GradSrc], residual: bool, need_dx: bool = True) -> List[GradSrc]:
+        """Backward of a ConvBlock (residual=False) or ResBlock y = x + B(x) (residual=True); returns sources for x."""
+        u1, u2 = units
+        g_a1, Gy = self._unit_bwd(ops, u2, srcs)
+        if not residual:
+            self.release(Gy)
+        g_x, G1 = self._unit_bwd(ops, u1, [g_a1], need_dx=need_dx)
+        self.release(G1)
+        out = []
+        if g_x is not None:
+            out.append(g_x)
+        if residual:
+            out.append(GradSrc(PV(Gy, u2.out.C), 0))
+        return out
+
+    def _plain_conv_bwd(self, ops, pc: PlainConv, srcs: List[GradSrc], need_dx: bool) -> Optional[GradSrc]:
+        """Backward of conv+bias (stem: stride 1; down: stride 2 via zero-insert).  Consumes srcs."""
+        B = self.B
+        C = pc.out.C
+        H, W = pc.out.H, pc.out.W
+        d = self.tmp(H, W, C)
+        g1 = srcs[0]
+        g2 = srcs[1] if len(srcs) > 1 else None
+        self.op(ops, "FOLD_SUM", [B, H, W, C, g1.pv.ldc, g1.pv.coff, g2.pv.ldc if g2 else 8, g2.pv.coff if g2 else 0, C, 0,
+                                  g1.fold, g2.fold if g2 else 0, self.pm],
+                p=[g1.pv.ref, g2.pv.ref if g2 else None, Ref(d)], tag=pc.conv)
+        for s in srcs:
+            self.release(s.pv.buf)
+        self.op(ops, "BIAS_GRAD", [B, H, W, C, C, 0], p=[Ref(d), self.gref(pc.conv + ".bias")], tag=pc.conv)
+        if pc.stride == 2:
+            full = self.tmp(2 * H, 2 * W, C)
+            self.op(ops, "ZERO_INSERT", [B, H, W, C, C, 0, C, 0], p=[Ref(d), Ref(full)], tag=pc.conv)
+            self.release(d)
+            d = full
+        self.e_wgrad(ops, pc.xin, PV(d, C), pc.conv)
+        dx = None
+        if need_dx:
+            cin = pc.xin.C
+            dpad = self.tmp(pc.xin.H, pc.xin.W, cin)
+            self.e_conv(ops, PV(d, C), self.convs[pc.conv]["Wd"], None, PV(dpad, cin), C, cin, tag=pc.conv + "/dgrad")
+            dx = GradSrc(PV(dpad, cin), 1)
+        self.release(d)
+        return dx
+
+    def emit_backward(self, ops, t: Tape, dpred: Buf, dx_out: Optional[Buf] = None, dx_channels: int = 6) -> None:
+        """Adjoint of emit_forward.  Accumulates parameter gradients (dWk scratch for 3x3 weights, grads_flat for the
+        rest); writes d(input) [B,dx_channels,H,W] fp32 into dx_out when given."""
+        cfg, B, H, W = self.cfg, self.B, self.H, self.W
+        x = t.head_in
+        G = self.tmp(H, W, x.C)
+        self.op(ops, "HEAD_BWD", [B, H, W, x.C, x.ldc, x.coff, x.C, 0, cfg.out_channels, rt.OUTACT[cfg.output_activation]],
+                p=[Ref(dpred), Ref(t.z), Ref(t.pred), x.ref, self.pref("head.weight"), Ref(G), self.gref("head.weight"),
+                   self.gref("head.bias")], tag="head")
+        srcs = [GradSrc(PV(G, x.C), 0)]
+        dcat: Dict[int, Buf] = {}
+        for i in reversed(range(cfg.depth)):
+            u = t.ups[i]
+            L = cfg.depth - 1 - i
+            C = u["C"]
+            if u["res"] is not None:
+                srcs = self._block_bwd(ops, u["res"], srcs, True)
+            srcs = self._block_bwd(ops, u["block"], srcs, False)
+            (gcat,) = srcs
+            dcat[L] = gcat.pv.buf                       # [.., 2C]: [0:C] -> upsample adjoint now, [C:2C] -> skip, later
+            self.retain(dcat[L])
+            h, w = u["xlow"].H, u["xlow"].W
+            glow = self.tmp(h, w, C)
+            self.op(ops, "UPSAMPLE2X_BWD", [B, h, w, C, 2 * C, 0, C, 0, 1, 1 if cfg.upsample == "bilinear" else 0, self.pm],
+                    p=[Ref(dcat[L]), Ref(glow)], tag=f"ups.{i}.up")
+            self.release(dcat[L])
+            srcs = [GradSrc(PV(glow, C), 0)]
+        for j in reversed(range(len(t.mids))):
+            srcs = self._block_bwd(ops, t.mids[j], srcs, True)
+        for L in reversed(range(cfg.depth)):
+            d = t.downs[L]
+            C = d["C"]
+            g = self._plain_conv_bwd(ops, d["down"], srcs, True)
+            srcs = [g, GradSrc(PV(dcat[L], C, C), 1)]
+            if d["res"] is not None:
+                srcs = self._block_bwd(ops, d["res"], srcs, True)
+            srcs = self._block_bwd(ops, d["block"], srcs, False)
+        need_dx = dx_out is not None
+        g = self._plain_conv_bwd(ops, t.stem, srcs, need_dx)
+        if need_dx:
+            self.op(ops, "UNPACK_GRAD", [B, H, W, 16, dx_channels, self.pm], p=[g.pv.ref, Ref(dx_out)], tag="dx")
+            self.release(g.pv.buf)
+
+    # -------------------------------------------------------------------------------------------- weights / optimiser
+    def emit_prep_weights(self, ops) -> None:
+        for name, c in self.convs.items():
+            self.op(ops, "PREP_WEIGHTS", [c["Cout"], c["Cin"], c["Cin_pad"], c["Cout_d"]],
+                    p=[self.pref(name + ".weight"), Ref(c["Wf"]), Ref(c["Wd"])], tag=name)
+
+    def emit_zero(self, ops, buf: Buf) -> None:
+        esz = {"f32": 4, "f64": 8}.get(buf.kind, 2 if self.dtype == rt.BF16 else 4)
+        nbytes = buf.numel * esz
+        self.op(ops, "ZERO", [nbytes & 0x7FFFFFFF, nbytes >> 31], p=[Ref(buf)], tag=buf.name)
+
+    def emit_zero_grads(self, ops) -> None:
+        self.emit_zero(ops, self.grads)
+        for c in self.convs.values():
+            self.emit_zero(ops, c["dWk"])
+
+    def emit_unprep(self, ops) -> None:
+        for name, c in self.convs.items():
+            self.op(ops, "UNPREP_WGRAD", [c["Cout"], c["Cin"], c["Cin_pad"], 0], p=[Ref(c["dWk"]), self.gref(name + ".weight")], tag=name)
+
+    # -------------------------------------------------------------------------------------------- loss
+    def loss_ops_args(self, lc, tgt: Tuple[Ref, int], in0: Tuple[Ref, int], emit: Tuple[Ref, int], coll: Tuple[Ref, int]):
+        flags = (1 if (lc.enable_divergence and lc.divergence_weight > 0) else 0) | \
+                (2 if (lc.enable_gradient and lc.gradient_weight > 0) else 0) | \
+                (4 if (lc.enable_emitter and lc.emitter_weight > 0) else 0)
+        i = [self.B, self.H, self.W, tgt[1], in0[1], emit[1], coll[1], rt.PAD[lc.padding_mode], rt.STENCIL[lc.stencil_mode], flags]
+        return i, flags
+
+    def emit_loss_fwd(self, ops, lc, pred: Buf, tgt, in0, emit, coll, sums: Buf, terms: Buf, accum: Optional[Buf], wk: float,
+                      gcnt: Optional[Ref] = None, world: int = 1) -> None:
+        i, flags = self.loss_ops_args(lc, tgt, in0, emit, coll)
+        self.emit_zero(ops, sums)
+        self.op(ops, "LOSS_REDUCE", i, f=[lc.grid_spacing], p=[Ref(pred), tgt[0], in0[0], emit[0], coll[0], Ref(sums)], tag="loss")
+        self.op(ops, "LOSS_FINALIZE", [self.B, self.H, self.W, flags, world],
+                f=[lc.mse_weight, lc.divergence_weight, lc.gradient_weight, lc.emitter_weight, wk],
+                p=[Ref(sums), gcnt, Ref(terms), Ref(accum) if accum is not None else None], tag="loss")
+
+    def emit_loss_grad(self, ops, lc, pred: Buf, tgt, in0, emit, coll, sums: Buf, dnext: Optional[Tuple[Ref, int]],
+                       gscale: Optional[Ref], dpred: Buf, wk: float, gcnt: Optional[Ref] = None, world: int = 1) -> None:
+        i, flags = self.loss_ops_args(lc, tgt, in0, emit, coll)
+        self.op(ops, "LOSS_GRAD", i + [world, dnext[1] if dnext else 0],
+                f=[lc.grid_spacing, lc.mse_weight, lc.divergence_weight, lc.gradient_weight, lc.emitter_weight, wk],
+                p=[Ref(pred), tgt[0], in0[0], emit[0], coll[0], Ref(sums), gcnt, dnext[0] if dnext else None, gscale, Ref(dpred)],
+                tag="loss")
+
+
+# ------------------------------------------------------------------------------------------------ binding
+def _torch_dtype(kind: str, plan_dtype: int):
+    import torch
+    if kind == "T":
+        return torch.bfloat16 if plan_dtype == rt.BF16 else torch.float32
+    return {"f32": torch.float32, "f64": torch.float64}[kind]
+
+
+def allocate(pb: PlanBuilder, device) -> int:
+    """Allocate every non-external buffer of the builder on `device` (zero-filled).  Returns bytes allocated."""
+    import torch
+    total = 0
+    for b in pb.bufs:
+        if b.external or b.tensor is not None:
+            continue
+        b.tensor = torch.zeros(b.shape, dtype=_torch_dtype(b.kind, pb.dtype), device=device)
+        total += b.tensor.numel() * b.tensor.element_size()
+    return total
+
+
+def lower(pb: PlanBuilder, recs: List[OpRec]) -> np.ndarray:
+    """OpRec list -> FnetOp array with absolute device pointers (all buffers must be bound)."""
+    arr = np.zeros(len(recs), dtype=rt.OP_DTYPE)
+    for k, r in enumerate(recs):
+        a = arr[k]
+        a["op"] = r.code
+        a["dtype"] = r.dtype
+        assert len(r.i) <= 30 and len(r.f) <= 8 and len(r.p) <= 10, r
+        a["i"][: len(r.i)] = r.i
+        a["f"][: len(r.f)] = r.f
+        for j, ref in enumerate(r.p):
+            if ref is None:
+                continue
+            t = ref.buf.tensor
+            if t is None:
+                raise RuntimeError(f"buffer {ref.buf.name} is not bound")
+            a["p"][j] = t.data_ptr() + ref.off * t.element_size()
+    return arr

@@ -1,0 +1,169 @@
+/*
+ * fluidnet_hip.h -- C ABI of libfluidnet_hip.so, the MI355X (gfx950) compute library behind
+ * the FluidNet hot path (UNet forward/backward, physics loss, K-step rollout loss, clip+Adam,
+ * autoregressive rollout).
+ *
+ * The reference (ohmatheus/FluidNet) has no FFI for this path: its boundary is the Python module
+ * API of ml/ (SURVEY.md section 8b).  This header is what a binding for that API would call; every
+ * entry point cites the reference interface it replaces (paths relative to the reference root).
+ * All pointers are DEVICE pointers unless named host_*; no torch types appear here.  Every launch
+ * goes to the hipStream_t passed in (as void*); nothing here allocates, frees or synchronises
+ * unless the comment says so.  Return value: 0 = ok, negative = FNET_E_* (see fnet_strerror).
+ *
+ * Data layout ("P-tensor"): activations live in HBM as channels-last, spatially PADDED arrays
+ *     [B][H+2][W+2][ldc]   element type fp32 or bf16,
+ * one ring of padding pixels filled according to the conv padding mode (zeros / replicate /
+ * reflect / circular), so that every 3x3 convolution is a "valid" convolution over the
+ * flattened pixel axis f = (n*(H+2)+y)*(W+2)+x with nine constant offsets.  A view selects
+ * channels [coff, coff+C) of a buffer with ldc channels (this is how skip-connection concat
+ * costs nothing).  Field planes at the API surface (inputs, targets, predictions) are plain
+ * fp32 NCHW like the reference's tensors.
+ */
+#ifndef FLUIDNET_HIP_H
+#define FLUIDNET_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FNET_ABI_VERSION 1
+
+/* error codes */
+#define FNET_OK 0
+#define FNET_E_BADARG (-1)   /* shape / alignment / enum violation (host-side check, nothing launched) */
+#define FNET_E_HIP (-2)      /* a HIP runtime call failed; fnet_last_hip_error() has the code */
+#define FNET_E_UNSUPPORTED (-3)
+
+/* element type of P-tensors */
+#define FNET_F32 0
+#define FNET_BF16 1
+
+/* padding mode (ml/models/unet.py:13 PaddingType; ml/training/physics_loss.py:32-33) */
+#define FNET_PAD_ZEROS 0
+#define FNET_PAD_REPLICATE 1
+#define FNET_PAD_REFLECT 2
+#define FNET_PAD_CIRCULAR 3
+
+/* activation (ml/models/unet.py:31-39) */
+#define FNET_ACT_RELU 0
+#define FNET_ACT_LEAKY 1
+#define FNET_ACT_GELU 2
+#define FNET_ACT_SILU 3
+#define FNET_ACT_IDENTITY 4
+
+/* output activation (ml/models/unet.py:296-301) */
+#define FNET_OUT_LINEAR_CLAMP 0
+#define FNET_OUT_SIGMOID_TANH 1
+
+/* stencil (ml/training/physics_loss.py:16) */
+#define FNET_STENCIL_FORWARD 0
+#define FNET_STENCIL_CENTRAL 1
+
+/* conv implementation selector */
+#define FNET_CONV_REF 0   /* plain fp32-accumulate FMA kernels, any dtype: the debugging / exact path */
+#define FNET_CONV_MFMA 1  /* bf16 MFMA implicit GEMM (32x32x16), LDS-staged halo rows */
+
+/* ---- op records ------------------------------------------------------------------------
+ * A "plan" is an array of FnetOp executed in order on one stream by fnet_plan_run().  The host
+ * side (fluidnet_amd/engine/plan.py) builds one plan per (UNetConfig, B, H, W, K) and replays
+ * it every step; slot meaning per opcode is documented in fluidnet_amd/csrc/fnet_ops.h.
+ */
+typedef struct FnetOp {
+    int32_t op;       /* FNET_OP_* */
+    int32_t dtype;    /* FNET_F32 / FNET_BF16 for the P-tensors of this op */
+    int32_t i[30];    /* integer arguments */
+    float f[8];       /* float arguments */
+    uint64_t p[10];   /* device pointers (0 = absent) */
+} FnetOp;
+
+enum FnetOpCode {
+    FNET_OP_NOP = 0,
+    FNET_OP_PACK_INPUT = 1,
+    FNET_OP_CONV3X3 = 2,
+    FNET_OP_WGRAD = 3,
+    FNET_OP_IN_STATS = 4,
+    FNET_OP_APPLY = 5,
+    FNET_OP_UPSAMPLE2X = 6,
+    FNET_OP_SUBSAMPLE_BIAS = 7,
+    FNET_OP_PAD_RING = 8,
+    FNET_OP_HEAD_FWD = 9,
+    FNET_OP_LOSS_REDUCE = 10,
+    FNET_OP_LOSS_FINALIZE = 11,
+    FNET_OP_LOSS_GRAD = 12,
+    FNET_OP_HEAD_BWD = 13,
+    FNET_OP_INACT_BWD_REDUCE = 14,
+    FNET_OP_INACT_BWD_APPLY = 15,
+    FNET_OP_AFFINE_GRAD = 16,
+    FNET_OP_FOLD_SUM = 17,
+    FNET_OP_BIAS_GRAD = 18,
+    FNET_OP_ZERO_INSERT = 19,
+    FNET_OP_UPSAMPLE2X_BWD = 20,
+    FNET_OP_UNPACK_GRAD = 21,
+    FNET_OP_ZERO = 22,
+    FNET_OP_PREP_WEIGHTS = 23,
+    FNET_OP_GRAD_NORM = 24,
+    FNET_OP_ADAM = 25,
+    FNET_OP_COPY_PLANES = 26,
+    FNET_OP_UNPREP_WGRAD = 27,
+    FNET_OP_STENCIL = 28,
+    FNET_OP_COUNT_
+};
+
+/* Library identity / diagnostics. */
+int fnet_abi_version(void);
+const char* fnet_strerror(int code);
+int fnet_last_hip_error(void);
+/* Device properties the host uses to size grids: [0]=CU count, [1]=max LDS per block, [2]=warp size, [3]=gfx major*100+minor. */
+int fnet_device_info(int32_t out[4]);
+
+/*
+ * Execute a plan: ops[0..n) in order on `stream`.  Replaces the chain of ATen calls under
+ * UNet.forward (ml/models/unet.py:281-303), PhysicsAwareLoss.forward
+ * (ml/training/physics_loss.py:210-278), Trainer._compute_rollout_loss
+ * (ml/training/trainer.py:311-385), loss.backward()/clip_grad_norm_/Adam.step
+ * (ml/training/trainer.py:190-195) and the rollout loop body (ml/scripts/simple_infer.py:226-260).
+ * Every op validates its arguments on the host before launching; on the first failure nothing
+ * further is launched and *failed_index (if non-null) receives the op index.
+ */
+int fnet_plan_run(const FnetOp* ops, int32_t n_ops, void* stream, int32_t* failed_index);
+
+/*
+ * hipGraph form of fnet_plan_run for launch-bound loops (the 600-frame rollout of
+ * ml/scripts/simple_infer.py:226-260; BASELINE config 5).  fnet_graph_create captures the plan on
+ * a private capture stream (this call allocates the graph objects and synchronises nothing else);
+ * fnet_graph_launch replays it `repeat` times on `stream`; fnet_graph_destroy frees it.
+ */
+int fnet_graph_create(const FnetOp* ops, int32_t n_ops, void** graph_out);
+int fnet_graph_launch(void* graph, void* stream, int32_t repeat);
+int fnet_graph_destroy(void* graph);
+
+/*
+ * Single-op conveniences used by the host mirror of the reference's free functions and by the
+ * parity tests (each is fnet_plan_run on a one-element plan):
+ *   fnet_spatial_gradients  <- compute_spatial_gradients  (ml/training/physics_loss.py:19-50)
+ *   fnet_divergence         <- compute_divergence         (ml/training/physics_loss.py:53-91)
+ * field planes are fp32 [B][H][W] contiguous.
+ */
+int fnet_spatial_gradients(const float* field, float* grad_x, float* grad_y, int32_t B, int32_t H, int32_t W,
+                           float dx, float dy, int32_t padding_mode, int32_t stencil_mode, void* stream);
+int fnet_divergence(const float* velx, const float* vely, float* div, int32_t B, int32_t H, int32_t W, float dx,
+                    float dy, int32_t padding_mode, int32_t stencil_mode, void* stream);
+
+/*
+ * HIP-event timing of a stream region, on the stream the kernels were launched on (bench.py
+ * uses this for roofline.achieved; torch.cuda.Event only sees torch's current stream).
+ * fnet_timer_create allocates two events; start/stop record them; elapsed_ms synchronises on the
+ * stop event and returns milliseconds.
+ */
+int fnet_timer_create(void** timer_out);
+int fnet_timer_start(void* timer, void* stream);
+int fnet_timer_stop(void* timer, void* stream);
+int fnet_timer_elapsed_ms(void* timer, float* ms_out);
+int fnet_timer_destroy(void* timer);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLUIDNET_HIP_H */

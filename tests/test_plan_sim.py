@@ -106,8 +106,13 @@ def test_clip_adam_step_matches_oracle():
         sim.run(plan.sections["opt"])
         _, _, raw = orc.train_step(p, m, v, step, cfg, lc, torch.from_numpy(x0), torch.from_numpy(y), torch.from_numpy(mk),
                                    lr=3e-3, clip_norm=0.05)
+        gn = float(torch.sqrt(sum((t.double() ** 2).sum() for t in raw.values())))
+        coef = min(1.0, 0.05 / (gn + 1e-6))
         for k_ in p:
-            noise = float(raw[k_].norm()) < 1e-6
-            # Adam divides by sqrt(v): elements with tiny gradients amplify fp32 noise up to a fraction of lr
-            tol = 3e-3 * step * 1.01 if noise else 0.1 * 3e-3 * step
-            assert (unpack(plan.pb, plan.pb.params.tensor, k_) - p[k_]).abs().max() < tol, (step, k_)
+            # Adam divides by sqrt(v) + 1e-8: elements whose (clipped) gradient is at the 1e-8 noise level take
+            # arbitrary steps of up to lr in ANY implementation, so only well-conditioned elements are matched tightly.
+            good = (raw[k_] * coef).abs() > 1e-5
+            d = (unpack(plan.pb, plan.pb.params.tensor, k_) - p[k_]).abs()
+            assert d.max() <= 3e-3 * step * 1.01, (step, k_)
+            if good.any():
+                assert d[good].max() < 3e-5 * step, (step, k_, float(d[good].max()))

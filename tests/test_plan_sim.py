@@ -115,4 +115,9 @@ def test_clip_adam_step_matches_oracle():
             d = (unpack(plan.pb, plan.pb.params.tensor, k_) - p[k_]).abs()
             assert d.max() <= 3e-3 * step * 1.01, (step, k_)
             if good.any():
-                assert d[good].max() < 3e-5 * step, (step, k_, float(d[good].max()))
+                assert d[good].max() < 3e-5, (step, k_, float(d[good].max()))
+        # re-synchronise the noise-level elements so that step 2 starts from identical state on both sides
+        from helpers import pack_params
+        plan.pb.params.tensor.copy_(pack_params(plan.pb, p))
+        plan.m.tensor.copy_(pack_params(plan.pb, m))
+        plan.v.tensor.copy_(pack_params(plan.pb, v))

@@ -1,0 +1,64 @@
+"""MFMA convolution / weight-gradient kernels on multi-tile shapes (several pixel tiles, N tiles, channel slices of wider
+buffers, partial tiles, images straddling tile boundaries) against the CPU twin, through the C ABI."""
+import numpy as np
+import pytest
+import torch
+
+from fluidnet_amd.engine import runtime as rt
+from fluidnet_amd.engine.plan import OpRec, PlanBuilder, PV, Ref, lower
+from helpers import tiny_cfg
+from lockstep import lockstep
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [
+    # B, H,  W,  Cin, Cout, ldc_in, coff_in, ldc_out, coff_out
+    (2, 64, 64, 64, 128, 64, 0, 128, 0),
+    (3, 20, 12, 32, 32, 96, 32, 64, 16),
+    (1, 128, 128, 16, 32, 16, 0, 32, 0),
+    (2, 16, 16, 256, 64, 256, 0, 64, 0),
+    (2, 30, 34, 48, 24, 48, 0, 24, 0),
+    (1, 8, 8, 128, 256, 256, 128, 256, 0),
+]
+
+
+def _mk(B, H, W, cin, cout, ldi, coi, ldo, coo, dtype, impl):
+    pb = PlanBuilder(tiny_cfg(base_channels=16), 1, 16, 16, dtype=dtype, conv_impl=impl)
+    pb.bufs.clear()
+    pb.B = B
+    g = torch.Generator().manual_seed(B * 1000 + H + cin)
+    T = torch.bfloat16 if dtype == "bf16" else torch.float32
+    src = pb.new_buf("src", (B, H + 2, W + 2, ldi), "T")
+    src.tensor = torch.randn(src.shape, generator=g).to(T)
+    wk = pb.new_buf("wk", (9, cout, cin), "T")
+    wk.tensor = (torch.randn(wk.shape, generator=g) / (3 * cin ** 0.5)).to(T)
+    bias = pb.new_buf("bias", (cout,), "f32")
+    bias.tensor = torch.randn(cout, generator=g)
+    dst = pb.new_buf("dst", (B, H + 2, W + 2, ldo), "T")
+    dst.tensor = torch.full(dst.shape, 7.0).to(T)
+    dout = pb.new_buf("dout", (B, H + 2, W + 2, ldo), "T")
+    d = torch.randn(dout.shape, generator=g)
+    d[:, 0] = 0; d[:, -1] = 0; d[:, :, 0] = 0; d[:, :, -1] = 0
+    dout.tensor = d.to(T)
+    dwk = pb.new_buf("dwk", (9, cout, cin), "f32")
+    dwk.tensor = torch.randn(dwk.shape, generator=g) * 0.01
+    ops = []
+    pb.e_conv(ops, PV(src, cin, coi), wk, Ref(bias), PV(dst, cout, coo), cin, cout, tag="conv")
+    npix = B * (H + 2) * (W + 2)
+    pb.op(ops, "WGRAD", [npix, W + 2, cin, ldi, coi, cout, ldo, coo, pb.impl_for(cin, cout), cin],
+          p=[Ref(src), Ref(dout), Ref(dwk)], tag="wgrad")
+    return pb, ops
+
+
+@pytest.mark.parametrize("shape", SHAPES, ids=[f"B{s[0]}_{s[1]}x{s[2]}_{s[3]}to{s[4]}" for s in SHAPES])
+def test_mfma_conv_and_wgrad(shape):
+    pb, ops = _mk(*shape, "bf16", "mfma")
+    failures = lockstep(pb, ops)
+    assert not failures, "\n".join(failures)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_ref_conv_and_wgrad(dtype):
+    pb, ops = _mk(2, 20, 12, 32, 40, 96, 32, 64, 16, dtype, "ref")
+    failures = lockstep(pb, ops)
+    assert not failures, "\n".join(failures)

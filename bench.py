@@ -1,0 +1,291 @@
+#!/usr/bin/env python3
+"""Headline benchmark: K4 UNet_medium 128^2 rollout-training samples/s (BASELINE.json metric, config[1]).
+
+    python bench.py --gpus N --steps K --warmup W            (N>1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --mode rollout                            (600-frame 256^2 x 64-scene inference rollout, frames/s)
+
+A step = one pass of the hot path over one synthetic batch resident in HBM: K UNet forwards + physics losses, BPTT
+backward, (RCCL gradient all-reduce), clip + Adam.  Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from fluidnet_amd.data.synthetic import simple_infer_masks, synth_rollout_batch  # noqa: E402
+from fluidnet_amd.engine import runtime as rt  # noqa: E402
+from fluidnet_amd.engine.rollout_plan import RolloutInferPlan  # noqa: E402
+from fluidnet_amd.engine.train_plan import RolloutTrainPlan  # noqa: E402
+from fluidnet_amd.models.unet import UNet, UNetConfig  # noqa: E402
+from fluidnet_amd.training.physics_loss import PhysicsAwareLoss  # noqa: E402
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0      # MI355X dense bf16 (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0
+
+
+def medium_cfg(dropout=0.1, depth=3):
+    return UNetConfig(in_channels=6, out_channels=3, base_channels=32, depth=depth, norm="instance", act="gelu", dropout=dropout,
+                      upsample="bilinear", downsample="stride", padding_mode="replicate", use_residual=True, bottleneck_blocks=1,
+                      output_activation="linear_clamp")
+
+
+def c2_loss(R):
+    return PhysicsAwareLoss(mse_weight=1.0, divergence_weight=0.01, gradient_weight=0.001, emitter_weight=0.01, grid_spacing=2.0 / R,
+                            enable_divergence=True, enable_gradient=True, enable_emitter=True, padding_mode="replicate",
+                            stencil_mode="forward")
+
+
+def dist_setup(n):
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    return rank, world, local
+
+
+def barrier(world):
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+class TrainStepper:
+    def __init__(self, B, R, K, precision, world, rank, lr=3e-4, conv_impl="auto"):
+        torch.manual_seed(42)
+        self.model = UNet(medium_cfg(), precision=precision, conv_impl=conv_impl).cuda()
+        self.world = world
+        self.lr = lr
+        self.plan = RolloutTrainPlan(self.model.cfg, c2_loss(R), B, R, R, K, dtype=precision, conv_impl=conv_impl, world=world,
+                                     weight_decay=1.10, clip_norm=1.0, seed=1234 + rank)
+        self.bytes = self.plan.bind(torch.device("cuda"), self.model.flat_params, self.model.flat_grads)
+        x0, y, mk = synth_rollout_batch(B, K, R, seed=1234 + rank)
+        self.plan.x0.tensor.copy_(torch.from_numpy(x0))
+        self.plan.y.tensor.copy_(torch.from_numpy(y))
+        self.plan.masks.tensor.copy_(torch.from_numpy(mk))
+        self.t = 0
+        if world > 1:
+            import torch.distributed as dist
+            self.dist = dist
+            dist.broadcast(self.model.flat_params, 0)
+
+    def step(self):
+        self.t += 1
+        p = self.plan
+        p.set_adam_scalars(self.lr, self.t)
+        p.set_dropout_seed(self.t * 7919 + 13)
+        if self.world == 1:
+            p.run(("fwd", "fin", "bwd", "opt"))
+            return
+        p.run(("fwd",))
+        p.gcnt.tensor.copy_(torch.stack([s.tensor[5] for s in p.sums]))
+        self.dist.all_reduce(p.gcnt.tensor)
+        p.run(("fin", "bwd"))
+        self.dist.all_reduce(p.pb.grads.tensor, op=self.dist.ReduceOp.AVG)
+        p.run(("opt",))
+
+
+def profile_ops(plan_arrays, recs_by_section):
+    """One extra instrumented step: HIP events (on the launch stream) around every op -> per-kernel-kind time and FLOPs."""
+    agg = {}
+    tm = [rt.Timer() for _ in range(2)]
+    for name, arr in plan_arrays.items():
+        recs = recs_by_section[name]
+        for k in range(len(arr)):
+            t = tm[0]
+            t.start()
+            rt.run_ops(arr[k:k + 1])
+            t.stop()
+            ms = t.elapsed_ms()
+            r = recs[k]
+            kind = rt.OPNAME[r.code]
+            if kind == "CONV3X3":
+                kind = "CONV3X3_" + ("MFMA" if r.i[8] == rt.CONV_MFMA else "REF")
+            if kind == "WGRAD":
+                kind = "WGRAD_" + ("MFMA" if r.i[8] == rt.CONV_MFMA else "REF")
+            a = agg.setdefault(kind, {"ms": 0.0, "n": 0, "flops": 0.0})
+            a["ms"] += ms
+            a["n"] += 1
+            a["flops"] += r.flops
+    return agg
+
+
+def cpu_baseline_train(K, R, budget_s=20.0):
+    """The CPU oracle (oracle/fluidnet_oracle.py, kind="port") timed on this host's cores on a bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import fluidnet_oracle as orc
+    cores = os.cpu_count() or 1
+    threads = min(cores, 16) if os.environ.get("OMP_NUM_THREADS") is None else int(os.environ["OMP_NUM_THREADS"])
+    torch.set_num_threads(threads)
+    B = 4
+    cfg = orc.medium_config(dropout=0.1)
+    lc = orc.LossConfig(1.0, 0.01, 0.001, 0.01, 2.0 / R, True, True, True, "replicate", "forward")
+    p = orc.make_params(cfg, seed=7)
+    m = {k: torch.zeros_like(v) for k, v in p.items()}
+    v = {k: torch.zeros_like(t) for k, t in p.items()}
+    x0, y, mk = orc.synth_batch(B, K, R, seed=1234)
+    args = (torch.from_numpy(x0), torch.from_numpy(y), torch.from_numpy(mk))
+    orc.train_step(p, m, v, 1, cfg, lc, *args, lr=3e-4, clip_norm=1.0)      # warm-up
+    t0 = time.time()
+    n = 0
+    while n < 2 or (time.time() - t0 < budget_s and n < 8):
+        orc.train_step(p, m, v, n + 2, cfg, lc, *args, lr=3e-4, clip_norm=1.0)
+        n += 1
+    dt = (time.time() - t0) / n
+    return {"value": round(B / dt, 4), "unit": "samples/s", "cores": threads, "kind": "port",
+            "sample": f"oracle/fluidnet_oracle.py train_step, UNet_medium K{K} {R}x{R}, batch {B}, fp32, {n} timed steps of {dt:.2f}s after 1 warm-up"}
+
+
+def cpu_baseline_rollout(R, budget_s=15.0):
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import fluidnet_oracle as orc
+    threads = min(os.cpu_count() or 1, 16) if os.environ.get("OMP_NUM_THREADS") is None else int(os.environ["OMP_NUM_THREADS"])
+    torch.set_num_threads(threads)
+    cfg = orc.medium_config(dropout=0.0)
+    p = orc.make_params(cfg, seed=7)
+    em, co = orc.simple_infer_masks(R, scale=R / 128.0)
+    B = 2
+    e = torch.from_numpy(em)[None].repeat(B, 1, 1)
+    c = torch.from_numpy(co)[None].repeat(B, 1, 1)
+    orc.rollout_infer(p, cfg, e, c, 1)
+    t0 = time.time()
+    n = 0
+    while n < 2 or (time.time() - t0 < budget_s and n < 20):
+        orc.rollout_infer(p, cfg, e, c, 1)
+        n += 1
+    dt = (time.time() - t0) / n
+    return {"value": round(B / dt, 3), "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": f"oracle rollout_infer, UNet_medium {R}x{R}, {B} scenes, fp32, {n} timed frames of {dt:.2f}s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--mode", choices=["train", "rollout"], default="train")
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--res", type=int, default=None)
+    ap.add_argument("--k", type=int, default=4)
+    ap.add_argument("--precision", default="bf16")
+    ap.add_argument("--conv-impl", default="auto")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    a = ap.parse_args()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); fluidnet_amd has no CPU path")
+    rank, world, local = dist_setup(a.gpus)
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+    rt.lib()
+
+    if a.mode == "train":
+        R = a.res or 128
+        steps = a.steps if a.steps is not None else 10
+        warm = a.warmup if a.warmup is not None else 3
+        st = TrainStepper(a.batch, R, a.k, a.precision, world, rank, conv_impl=a.conv_impl)
+        for _ in range(warm):
+            st.step()
+        barrier(world)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            st.step()
+        barrier(world)
+        dt = time.perf_counter() - t0
+        tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        if world > 1:
+            st.dist.all_reduce(tmax, op=st.dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+        loss = st.plan.loss_dict()
+        ms_step = dt / steps * 1e3
+        value = world * a.batch * steps / dt
+        out = {"metric": "train samples/sec (K4 UNet 128^2)" if (a.k == 4 and R == 128) else f"train samples/sec (K{a.k} UNet {R}^2)",
+               "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": steps, "warmup": warm,
+               "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": a.precision, "data": "synthetic",
+               "config": {"workload": f"UNet_medium K{a.k} rollout training {R}x{R}, batch {a.batch}/GPU, MSE+divergence+gradient+emitter, "
+                                      f"BPTT through all K, clip 1.0 + Adam, dropout 0.1", "global_batch": a.batch * world,
+                          "parallelism": f"dp{world}", "final_loss": round(loss["total"], 6),
+                          "hbm_bytes_allocated": st.bytes}}
+        flops_step = sum(r.flops for s in st.plan.sections.values() for r in s)
+        out["config"]["algorithmic_tflop_per_step"] = round(flops_step / 1e12, 4)
+        out["config"]["end_to_end_tflops"] = round(flops_step * steps / dt / 1e12 * 1.0, 2)
+        if rank == 0 and not a.no_profile:
+            agg = profile_ops(st.plan._lowered, st.plan.sections)
+            tot = sum(v["ms"] for v in agg.values())
+            conv = agg.get("CONV3X3_MFMA") or agg.get("CONV3X3_REF")
+            ach = conv["flops"] / (conv["ms"] * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "kernel": "k_conv3x3_mfma (forward + data-gradient launches)",
+                               "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                               "launches_per_step": conv["n"], "avg_launch_ms": round(conv["ms"] / conv["n"], 4),
+                               "algorithmic_gflop_per_launch": round(conv["flops"] / conv["n"] / 1e9, 3)}
+            out["breakdown_ms_per_step"] = {k: round(v["ms"], 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
+            out["breakdown_ms_per_step"]["_sum"] = round(tot, 3)
+            wg = agg.get("WGRAD_MFMA")
+            if wg:
+                out["wgrad_tflops"] = round(wg["flops"] / (wg["ms"] * 1e-3) / 1e12, 2)
+        if rank == 0 and world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_train(a.k, R)
+    else:
+        R = a.res or 256
+        frames = a.steps if a.steps is not None else 600
+        warm = a.warmup if a.warmup is not None else 10
+        torch.manual_seed(42)
+        model = UNet(medium_cfg(dropout=0.0), precision=a.precision, conv_impl=a.conv_impl).cuda().eval()
+        plan = RolloutInferPlan(model.cfg, a.batch, R, R, params_flat=model.flat_params, dtype=a.precision, conv_impl=a.conv_impl)
+        em, co = simple_infer_masks(R, scale=R / 128.0)
+        e = torch.from_numpy(em).cuda()[None].repeat(a.batch, 1, 1)
+        c = torch.from_numpy(co).cuda()[None].repeat(a.batch, 1, 1)
+        plan.reset(e, c)
+        plan.step(warm)
+        barrier(world)
+        t0 = time.perf_counter()
+        plan.step(frames)
+        barrier(world)
+        dt = time.perf_counter() - t0
+        tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        if world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+        value = world * a.batch * frames / dt
+        fl = sum(r.flops for r in plan.frame)
+        out = {"metric": "rollout frames/sec", "value": round(value, 1), "unit": "scene-frames/s", "n_gpus": world, "steps": frames,
+               "warmup": warm, "ms_per_step": round(dt / frames * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
+               "config": {"workload": f"{frames}-frame autoregressive rollout, UNet_medium {R}x{R}, {a.batch} scenes/GPU, hipGraph-captured frame",
+                          "steps_per_s": round(frames / dt, 2), "parallelism": f"replicas{world}",
+                          "end_to_end_tflops": round(fl * frames / dt / 1e12, 2), "state_finite": bool(torch.isfinite(plan.cur.tensor).all())}}
+        if rank == 0 and not a.no_profile:
+            agg = profile_ops({"frame": plan._frame}, {"frame": plan.frame})
+            conv = agg.get("CONV3X3_MFMA") or agg.get("CONV3X3_REF")
+            ach = conv["flops"] / (conv["ms"] * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "kernel": "k_conv3x3_mfma", "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS,
+                               "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                               "launches_per_step": conv["n"], "avg_launch_ms": round(conv["ms"] / conv["n"], 4)}
+            out["breakdown_ms_per_step"] = {k: round(v["ms"], 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
+        if rank == 0 and world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_rollout(R)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -80,6 +80,7 @@ class OpRec:
     p: List[Optional[Ref]] = field(default_factory=list)
     dtype: int = 0
     tag: str = ""
+    flops: float = 0.0             # algorithmic (useful) FLOPs of this launch, for roofline accounting
 
 
 @dataclass(eq=False)
@@ -278,11 +279,19 @@ class PlanBuilder:
         self.op(ops, "PACK_INPUT", [self.B, dst.shape[1] - 2, dst.shape[2] - 2, dst.shape[3], self.pm] + [s for _, s in planes],
                 p=[r for r, _ in planes] + [Ref(dst)], tag=dst.name)
 
+    def conv_flops(self, name: str, H: int, W: int) -> float:
+        """2*MAC of the real convolution `name` evaluated on an HxW input grid (real channels; stride-2 convs count
+        their H/2 x W/2 outputs) -- SURVEY.md section 8d's convention."""
+        c = self.convs[name.split("/")[0]]
+        fl = 2.0 * self.B * H * W * 9 * c["Cin"] * c["Cout"]
+        return fl / 4 if name.split("/")[0].endswith(".down") else fl
+
     def e_conv(self, ops, src: PV, wbuf: Buf, bias: Optional[Ref], dst: PV, cin: int, cout: int, tag=""):
         npix = self.B * (src.H + 2) * (src.W + 2)
         assert (dst.H, dst.W) == (src.H, src.W) and src.C == cin and dst.C == cout, (tag, src.C, cin, dst.C, cout)
         self.op(ops, "CONV3X3", [npix, src.W + 2, cin, src.ldc, src.coff, cout, dst.ldc, dst.coff, self.impl_for(cin, cout)],
                 p=[src.ref, Ref(wbuf), bias, dst.ref], tag=tag)
+        ops[-1].flops = self.conv_flops(tag, src.H, src.W)
 
     def e_wgrad(self, ops, src: PV, dout: PV, conv: str):
         c = self.convs[conv]
@@ -291,6 +300,7 @@ class PlanBuilder:
         self.op(ops, "WGRAD", [npix, src.W + 2, src.C, src.ldc, src.coff, dout.C, dout.ldc, dout.coff,
                                self.impl_for(src.C, dout.C), c["Cin_pad"]],
                 p=[src.ref, dout.ref, Ref(c["dWk"])], tag=conv)
+        ops[-1].flops = self.conv_flops(conv, src.H, src.W)
 
     def e_stats(self, ops, raw: PV, st: Buf):
         self.op(ops, "IN_STATS", [self.B, raw.H, raw.W, raw.C, raw.ldc, raw.coff], f=[1e-5], p=[raw.ref, Ref(st)])

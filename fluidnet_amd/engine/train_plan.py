@@ -125,6 +125,12 @@ class RolloutTrainPlan:
             self._lowered = {k: lower(self.pb, v) for k, v in self.sections.items()}
         return nbytes
 
+    def set_dropout_seed(self, seed: int) -> None:
+        """New Dropout2d masks for the next step (the hash also mixes in the application index and the layer)."""
+        for n in ("fwd", "bwd"):
+            if n in self._lowered:
+                rt.patch_seed(self._lowered[n], seed)
+
     def run(self, names=("fwd", "fin", "bwd", "opt"), stream=None) -> None:
         for n in names:
             rt.run_ops(self._lowered[n], stream)

@@ -1,0 +1,141 @@
+"""The reference's own 16 property tests (ml/tests/test_physics_loss.py:13-208) run against the HIP loss path through
+the drop-in API, plus the G4 golden matrix (all padding modes x stencils x mask kinds: values and d/d(outputs))."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from fluidnet_amd.training.physics_loss import (PhysicsAwareLoss, compute_divergence, compute_spatial_gradients,
+                                                divergence_loss, emitter_spawn_loss, gradient_loss)
+
+pytestmark = pytest.mark.gpu
+D = "cuda"
+
+
+def _ramp(n, axis):
+    a = torch.arange(n).float()
+    g = a[None, :].expand(n, n) if axis == "x" else a[:, None].expand(n, n)
+    return g[None].expand(2, -1, -1).contiguous().to(D)
+
+
+def test_constant_field_has_zero_gradient():
+    gx, gy = compute_spatial_gradients(torch.ones(2, 32, 32, device=D), padding_mode="replicate")
+    assert gx.abs().max() < 1e-6 and gy.abs().max() < 1e-6
+
+
+def test_linear_field_has_constant_gradient():
+    gx, gy = compute_spatial_gradients(_ramp(32, "x"), dx=1.0, dy=1.0, padding_mode="replicate")
+    assert abs(float(gx.mean()) - 1.0) < 0.1 and abs(float(gy.mean())) < 0.1
+
+
+def test_gradient_shape_preservation():
+    f = torch.randn(4, 64, 64, device=D)
+    gx, gy = compute_spatial_gradients(f)
+    assert gx.shape == f.shape and gy.shape == f.shape
+
+
+def test_divergence_free_field():
+    div = compute_divergence(-_ramp(32, "y"), _ramp(32, "x"), dx=1.0, dy=1.0, padding_mode="replicate")
+    assert div.abs().mean() < 0.1
+
+
+def test_divergence_loss_excludes_emitters():
+    l = divergence_loss(torch.randn(2, 32, 32, device=D), torch.randn(2, 32, 32, device=D), torch.ones(2, 32, 32, device=D),
+                        padding_mode="replicate")
+    assert abs(float(l)) < 1e-6
+
+
+def test_divergence_loss_non_zero_for_divergent_field():
+    assert float(divergence_loss(_ramp(32, "x"), _ramp(32, "y"), torch.zeros(2, 32, 32, device=D), padding_mode="replicate")) > 0
+
+
+def test_identical_fields_have_zero_loss():
+    d = torch.randn(2, 64, 64, device=D)
+    assert abs(float(gradient_loss(d, d.clone(), padding_mode="replicate"))) < 1e-6
+
+
+def test_different_fields_have_nonzero_loss():
+    assert float(gradient_loss(torch.randn(2, 64, 64, device=D), torch.randn(2, 64, 64, device=D), padding_mode="replicate")) > 0
+
+
+def test_gradient_loss_excludes_emitters_and_colliders():
+    one = torch.ones(2, 32, 32, device=D)
+    l = gradient_loss(torch.randn(2, 32, 32, device=D), torch.randn(2, 32, 32, device=D), one, one, padding_mode="replicate")
+    assert abs(float(l)) < 1e-6
+
+
+def test_gradient_loss_with_partial_masking():
+    p = torch.zeros(2, 32, 32)
+    t = torch.zeros(2, 32, 32)
+    p[:, :10] = torch.linspace(0, 10, 10)[None, :, None]
+    p[:, 10:22] = 1.0
+    t[:, 10:22] = 1.0
+    p[:, 22:] = torch.linspace(10, 0, 10)[None, :, None]
+    e = torch.zeros(2, 32, 32)
+    e[:, :10] = 1
+    c = torch.zeros(2, 32, 32)
+    c[:, 22:] = 1
+    l = gradient_loss(p.to(D), t.to(D), e.to(D), c.to(D), padding_mode="replicate")
+    assert float(l) >= 0 and torch.isfinite(l)
+
+
+def _rand_case():
+    o, t, i = torch.randn(2, 3, 64, 64), torch.randn(2, 3, 64, 64), torch.randn(2, 6, 64, 64)
+    i[:, 4] = (i[:, 4] > 0).float()
+    i[:, 5] = (i[:, 5] > 0).float()
+    return o.to(D), t.to(D), i.to(D)
+
+
+def test_forward_returns_loss_and_dict():
+    loss, d = PhysicsAwareLoss()(*_rand_case())
+    assert isinstance(loss, torch.Tensor) and loss.ndim == 0 and isinstance(d, dict)
+    assert {"total", "mse", "divergence", "gradient"} <= set(d)
+
+
+def test_disable_flags_work():
+    _, d = PhysicsAwareLoss(enable_divergence=False, enable_gradient=False)(*_rand_case())
+    assert "divergence" not in d and "gradient" not in d and "mse" in d
+
+
+def test_loss_components_are_finite():
+    loss, d = PhysicsAwareLoss()(*_rand_case())
+    assert torch.isfinite(loss) and all(np.isfinite(v) for v in d.values())
+
+
+@pytest.mark.parametrize("padding_mode", ["zeros", "replicate", "reflect"])
+def test_gradient_computation_with_padding_modes(padding_mode):
+    f = torch.randn(2, 32, 32, device=D)
+    gx, gy = compute_spatial_gradients(f, padding_mode=padding_mode)
+    assert gx.shape == f.shape and torch.isfinite(gx).all() and torch.isfinite(gy).all()
+
+
+def test_g4_golden_matrix(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g4_loss_matrix.npz"))
+    out, tgt, inp = (torch.from_numpy(g[k]).to(D) for k in ("out", "tgt", "inp"))
+    R = out.shape[2]
+    e, c = g["emit_partial"], g["coll_partial"]
+    kinds = {"partial": (e, c), "none": (np.zeros_like(e), np.zeros_like(c)), "all_emitter": (np.ones_like(e), np.zeros_like(c))}
+    for pm in ("zeros", "replicate", "reflect", "circular"):
+        for st in ("forward", "central"):
+            gx, gy = compute_spatial_gradients(out[:, 0], 0.5, 0.25, pm, st)
+            div = compute_divergence(out[:, 1], out[:, 2], 0.5, 0.25, pm, st)
+            assert np.abs(gx.cpu().numpy() - g[f"{pm}/{st}/gx"]).max() < 1e-5
+            assert np.abs(gy.cpu().numpy() - g[f"{pm}/{st}/gy"]).max() < 1e-5
+            assert np.abs(div.cpu().numpy() - g[f"{pm}/{st}/div"]).max() < 2e-5
+            for mk, (em, co) in kinds.items():
+                i2 = inp.clone()
+                i2[:, 4], i2[:, 5] = torch.from_numpy(em).to(D), torch.from_numpy(co).to(D)
+                o = out.clone().requires_grad_(True)
+                crit = PhysicsAwareLoss(1.0, 0.3, 0.2, 0.4, 2.0 / R, True, True, True, pm, st)
+                loss, d = crit(o, tgt, i2)
+                loss.backward()
+                pre = f"{pm}/{st}/{mk}"
+                assert abs(float(loss) - float(g[f"{pre}/total"])) <= 2e-6 * max(1, abs(float(g[f"{pre}/total"]))), pre
+                for k in ("mse", "divergence", "gradient", "emitter"):
+                    assert abs(d[k] - float(g[f"{pre}/{k}"])) <= 2e-6 * max(1, abs(float(g[f"{pre}/{k}"]))), (pre, k)
+                assert np.abs(o.grad.cpu().numpy() - g[f"{pre}/dout"]).max() < 2e-7 + 1e-5 * np.abs(g[f"{pre}/dout"]).max(), pre
+    v = gradient_loss(out[:, 0], tgt[:, 0], padding_mode="replicate", mode="central")
+    assert abs(float(v) - float(g["nomask_gradient_loss"])) < 1e-5 * max(1, float(g["nomask_gradient_loss"]))
+    v = emitter_spawn_loss(out[:, 0:1], inp[:, 0:1], torch.from_numpy(e[:, None]).to(D))
+    assert abs(float(v) - float(g["emitter_loss"])) < 1e-7

@@ -98,10 +98,11 @@ class TrainStepper:
         p.run(("opt",))
 
 
-def profile_ops(plan_arrays, recs_by_section):
+def profile_ops(plan_arrays, recs_by_section, dump_path=None):
     """One extra instrumented step: HIP events (on the launch stream) around every op -> per-kernel-kind time and FLOPs."""
     agg = {}
     tm = [rt.Timer() for _ in range(2)]
+    rows = []
     for name, arr in plan_arrays.items():
         recs = recs_by_section[name]
         for k in range(len(arr)):
@@ -112,6 +113,7 @@ def profile_ops(plan_arrays, recs_by_section):
             ms = t.elapsed_ms()
             r = recs[k]
             kind = rt.OPNAME[r.code]
+            rows.append((name, k, kind, r.tag, ms, r.flops, list(r.i[:12])))
             if kind == "CONV3X3":
                 kind = "CONV3X3_" + ("MFMA" if r.i[8] == rt.CONV_MFMA else "REF")
             if kind == "WGRAD":
@@ -120,6 +122,12 @@ def profile_ops(plan_arrays, recs_by_section):
             a["ms"] += ms
             a["n"] += 1
             a["flops"] += r.flops
+    if dump_path:
+        os.makedirs(os.path.dirname(dump_path) or ".", exist_ok=True)
+        with open(dump_path, "w") as f:
+            f.write("section,idx,op,tag,ms,gflop,tflops,i\n")
+            for (name, k, kind, tag, ms, fl, iv) in rows:
+                f.write(f"{name},{k},{kind},{tag},{ms:.4f},{fl / 1e9:.3f},{(fl / (ms * 1e-3) / 1e12) if ms > 0 else 0:.1f},{' '.join(map(str, iv))}\n")
     return agg
 
 
@@ -184,6 +192,7 @@ def main():
     ap.add_argument("--conv-impl", default="auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--dump-ops", default=None, help="write per-op HIP-event timings of the instrumented step to this CSV")
     a = ap.parse_args()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); fluidnet_amd has no CPU path")
@@ -224,7 +233,7 @@ def main():
         out["config"]["algorithmic_tflop_per_step"] = round(flops_step / 1e12, 4)
         out["config"]["end_to_end_tflops"] = round(flops_step * steps / dt / 1e12 * 1.0, 2)
         if rank == 0 and not a.no_profile:
-            agg = profile_ops(st.plan._lowered, st.plan.sections)
+            agg = profile_ops(st.plan._lowered, st.plan.sections, a.dump_ops)
             tot = sum(v["ms"] for v in agg.values())
             conv = agg.get("CONV3X3_MFMA") or agg.get("CONV3X3_REF")
             ach = conv["flops"] / (conv["ms"] * 1e-3) / 1e12
@@ -271,7 +280,7 @@ def main():
                           "steps_per_s": round(frames / dt, 2), "parallelism": f"replicas{world}",
                           "end_to_end_tflops": round(fl * frames / dt / 1e12, 2), "state_finite": bool(torch.isfinite(plan.cur.tensor).all())}}
         if rank == 0 and not a.no_profile:
-            agg = profile_ops({"frame": plan._frame}, {"frame": plan.frame})
+            agg = profile_ops({"frame": plan._frame}, {"frame": plan.frame}, a.dump_ops)
             conv = agg.get("CONV3X3_MFMA") or agg.get("CONV3X3_REF")
             ach = conv["flops"] / (conv["ms"] * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "kernel": "k_conv3x3_mfma", "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS,

@@ -51,8 +51,26 @@ __global__ __launch_bounds__(256) void k_pack_input(PackArgs a, T* dst, int B, i
     }
 }
 
+// ------------------------------------------------------------------ channel-group thread mapping ("cg kernels")
+// The norm/activation kernels below give every thread a FIXED group of 8 channels (cg = tid % groups) and let it walk
+// pixels with stride ppi = 256 / groups, so the per-channel constants (mean, rstd, gamma, beta, dropout multiplier, the
+// backward sums) are loaded and folded into two FMA coefficients once per thread instead of once per 16 bytes.  A wave
+// still covers 64 consecutive 16-B pieces of the pixel-major buffer, so global accesses stay fully coalesced.
+// grid = (chunks per image, B); a block owns a contiguous pixel range of one image.
+struct CgMap {
+    int groups, ppi, cg, px;
+    bool active;
+    __device__ __forceinline__ CgMap(int C) {
+        groups = C >> 3;
+        ppi = kThreads / groups;
+        cg = threadIdx.x % groups;
+        px = threadIdx.x / groups;
+        active = px < ppi;
+    }
+};
+
 // ------------------------------------------------------------------ IN_STATS
-// one block per (n, 8-channel group): exact two-pass mean / biased variance over the interior H*W
+// fp32 plans: one block per (n, 8-channel group), exact two-pass mean / biased variance over the interior H*W
 template <typename T>
 __global__ __launch_bounds__(256) void k_in_stats(const T* raw, float2* stats, int B, int H, int W, int C, int ldc, int coff, float eps) {
     __shared__ float red[32];
@@ -93,47 +111,104 @@ __global__ __launch_bounds__(256) void k_in_stats(const T* raw, float2* stats, i
     }
 }
 
+// bf16 plans: one coalesced pass; every block writes its per-channel (sum, sumsq) partials to part[n][chunk][C][2] and
+// k_in_finalize adds them in chunk order (no atomics: the forward pass stays bit-reproducible run to run).
+template <typename T>
+__global__ __launch_bounds__(256) void k_in_stats_part(const T* raw, float* part, int H, int W, int C, int ldc, int coff, int q_per_block) {
+    __shared__ float red[kThreads * 16];
+    const CgMap m(C);
+    const int n = blockIdx.y, HW = H * W, Wp = W + 2;
+    const int q0 = blockIdx.x * q_per_block, q1 = min(HW, q0 + q_per_block);
+    float s[8], t[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { s[k] = 0.f; t[k] = 0.f; }
+    if (m.active) {
+        const T* base = raw + (size_t)n * (H + 2) * Wp * ldc + coff + m.cg * 8;
+        int q = q0 + m.px;
+        int y = q / W, x = q - y * W;
+        for (; q < q1; q += m.ppi) {
+            Vec8<T> v;
+            v.load(base + ((size_t)(y + 1) * Wp + (x + 1)) * ldc);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { s[k] += v.v[k]; t[k] = fmaf(v.v[k], v.v[k], t[k]); }
+            x += m.ppi;
+            while (x >= W) { x -= W; ++y; }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { red[threadIdx.x * 16 + k] = s[k]; red[threadIdx.x * 16 + 8 + k] = t[k]; }
+    __syncthreads();
+    float* dst = part + ((size_t)n * gridDim.x + blockIdx.x) * C * 2;
+    for (int idx = threadIdx.x; idx < m.groups * 16; idx += kThreads) {
+        const int cg = idx >> 4, k = idx & 15;
+        float a = 0.f;
+        for (int p = 0; p < m.ppi; ++p) a += red[(p * m.groups + cg) * 16 + k];
+        dst[(cg * 8 + (k & 7)) * 2 + (k >> 3)] = a;
+    }
+}
+__global__ __launch_bounds__(256) void k_in_finalize(const float2* part, float2* stats, int B, int C, int chunks, float inv_hw, float eps) {
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    if (i >= B * C) return;
+    const int n = i / C, c = i - n * C;
+    float sx = 0.f, sq = 0.f;
+    for (int j = 0; j < chunks; ++j) {
+        const float2 v = part[((size_t)n * chunks + j) * C + c];
+        sx += v.x; sq += v.y;
+    }
+    const float mean = sx * inv_hw;
+    const float var = fmaxf(sq * inv_hw - mean * mean, 0.f);
+    stats[i] = make_float2(mean, rsqrtf(var + eps));
+}
+
 // ------------------------------------------------------------------ APPLY
 // dst[n,y,x,c] = act(gamma*(raw[src]-mean)*rstd+beta) * drop(n,c) + res[src], over the padded domain
 template <typename T>
 __global__ __launch_bounds__(256) void k_apply(const T* raw, const float2* stats, const float* gamma, const float* beta, const T* res, T* dst,
-                        int B, int H, int W, int C, int ldc_raw, int coff_raw, int ldc_res, int coff_res, int ldc_dst,
-                        int coff_dst, int act, int pm, uint32_t site, uint32_t seed, float drop_p) {
-    const int Hp = H + 2, Wp = W + 2, groups = C >> 3;
-    const int row = blockIdx.x;
-    const int n = row / Hp, y = row % Hp;
-    const int item = blockIdx.y * kThreads + threadIdx.x;
-    if (item >= Wp * groups) return;
-    const int x = item / groups, cg = item - x * groups;
-    const int c0 = cg * 8;
-    T* d = dst + ((size_t)row * Wp + x) * ldc_dst + coff_dst + c0;
-    const int sy = pad_src(y - 1, H, pm), sx = pad_src(x - 1, W, pm);
-    Vec8<T> o;
-    if (sy < 0 || sx < 0) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) o.v[k] = 0.f;
-        o.store(d);
-        return;
-    }
-    const size_t spix = ((size_t)n * Hp + sy + 1) * Wp + sx + 1;
-    Vec8<T> r;
-    r.load(raw + spix * ldc_raw + coff_raw + c0);
+                        int H, int W, int C, int ldc_raw, int coff_raw, int ldc_res, int coff_res, int ldc_dst,
+                        int coff_dst, int act, int pm, uint32_t site, uint32_t seed, float drop_p, int p_per_block) {
+    const CgMap m(C);
+    if (!m.active) return;
+    const int n = blockIdx.y, Hp = H + 2, Wp = W + 2, c0 = m.cg * 8;
+    const int p0 = blockIdx.x * p_per_block, p1 = min(Hp * Wp, p0 + p_per_block);
+    float ca[8], cb[8], dsc[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        float u = r.v[k];
         if (stats) {
             const float2 ms = stats[(size_t)n * C + c0 + k];
-            u = (u - ms.x) * ms.y * gamma[c0 + k] + beta[c0 + k];
-        }
-        o.v[k] = act_fwd(u, act) * drop_scale(seed, site, n, c0 + k, drop_p);
+            ca[k] = ms.y * gamma[c0 + k];
+            cb[k] = fmaf(-ms.x, ca[k], beta[c0 + k]);
+        } else { ca[k] = 1.f; cb[k] = 0.f; }
+        dsc[k] = drop_scale(seed, site, n, c0 + k, drop_p);
     }
-    if (res) {
-        Vec8<T> q;
-        q.load(res + spix * ldc_res + coff_res + c0);
+    const size_t img = (size_t)n * Hp * Wp;
+    const T* rbase = raw + img * ldc_raw + coff_raw + c0;
+    const T* sbase = res ? res + img * ldc_res + coff_res + c0 : nullptr;
+    T* dbase = dst + img * ldc_dst + coff_dst + c0;
+    int p = p0 + m.px;
+    int y = p / Wp, x = p - y * Wp;
+    for (; p < p1; p += m.ppi) {
+        const int sy = pad_src(y - 1, H, pm), sx = pad_src(x - 1, W, pm);
+        Vec8<T> o;
+        if (sy < 0 || sx < 0) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) o.v[k] += q.v[k];
+            for (int k = 0; k < 8; ++k) o.v[k] = 0.f;
+        } else {
+            const size_t sp = (size_t)(sy + 1) * Wp + sx + 1;
+            Vec8<T> r;
+            r.load(rbase + sp * ldc_raw);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o.v[k] = act_fwd(fmaf(r.v[k], ca[k], cb[k]), act) * dsc[k];
+            if (sbase) {
+                Vec8<T> q;
+                q.load(sbase + sp * ldc_res);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) o.v[k] += q.v[k];
+            }
+        }
+        o.store(dbase + (size_t)p * ldc_dst);
+        x += m.ppi;
+        while (x >= Wp) { x -= Wp; ++y; }
     }
-    o.store(d);
 }
 
 // ------------------------------------------------------------------ gradient read with ring fold
@@ -161,61 +236,70 @@ __device__ __forceinline__ void fold_read8(const T* g, int n, int y, int x, int 
 }
 
 // ------------------------------------------------------------------ INACT_BWD_REDUCE (pass 1)
-// G = fold(g1) + fold(g2); dz = G*drop*act'(u); S1 = sum dz, S2 = sum dz*xhat per (n,c).  Writes G (interior).
+// G = fold(g1) + fold(g2); dz = G*drop*act'(u); S1 = sum dz, S2 = sum dz*xhat per (n,c).  Writes G (interior) and adds the
+// block's partial sums into S (zeroed by the plan before this op).
 template <typename T>
 __global__ __launch_bounds__(256) void k_inact_bwd_reduce(const T* g1, const T* g2, const T* raw, const float2* stats, const float* gamma,
-                                   const float* beta, T* G, float2* S, int B, int H, int W, int C, int ldc_g1,
+                                   const float* beta, T* G, float* S, int H, int W, int C, int ldc_g1,
                                    int coff_g1, int ldc_g2, int coff_g2, int ldc_raw, int coff_raw, int ldc_G, int coff_G,
-                                   int fold1, int fold2, int act, int pm, uint32_t site, uint32_t seed, float drop_p) {
-    __shared__ float red[32];
-    const int groups = C >> 3;
-    const int n = blockIdx.x / groups, cg = blockIdx.x % groups, c0 = cg * 8;
-    const int Hp = H + 2, Wp = W + 2, HW = H * W;
-    float mean[8], rstd[8], gam[8], bet[8], dsc[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const float2 ms = stats[(size_t)n * C + c0 + k];
-        mean[k] = ms.x; rstd[k] = ms.y; gam[k] = gamma[c0 + k]; bet[k] = beta[c0 + k];
-        dsc[k] = drop_scale(seed, site, n, c0 + k, drop_p);
-    }
-    float s[8];  // interleave S1 (4) / S2 (4)? no: two separate reductions of 8
-    float t[8];
+                                   int fold1, int fold2, int act, int pm, uint32_t site, uint32_t seed, float drop_p, int q_per_block) {
+    __shared__ float red[kThreads * 16];
+    const CgMap m(C);
+    const int n = blockIdx.y, Hp = H + 2, Wp = W + 2, HW = H * W, c0 = m.cg * 8;
+    const int q0 = blockIdx.x * q_per_block, q1 = min(HW, q0 + q_per_block);
+    float s[8], t[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) { s[k] = 0.f; t[k] = 0.f; }
-    for (int idx = threadIdx.x; idx < HW; idx += kThreads) {
-        const int y = idx / W, x = idx - y * W;
-        float acc[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) acc[k] = 0.f;
-        fold_read8<T>(g1 + coff_g1 + c0, n, y, x, H, W, ldc_g1, pm, fold1, acc);
-        if (g2) fold_read8<T>(g2 + coff_g2 + c0, n, y, x, H, W, ldc_g2, pm, fold2, acc);
-        const size_t pix = ((size_t)n * Hp + y + 1) * Wp + x + 1;
-        Vec8<T> go;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) go.v[k] = acc[k];
-        go.store(G + pix * ldc_G + coff_G + c0);
-        Vec8<T> r;
-        r.load(raw + pix * ldc_raw + coff_raw + c0);
+    if (m.active) {
+        float xa[8], xb[8], gam[8], bet[8], dsc[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            // use the value as stored (bf16-rounded in bf16 mode) so that pass 2 sees the same G
-            const float xh = (r.v[k] - mean[k]) * rstd[k];
-            const float u = xh * gam[k] + bet[k];
-            float gq = go.v[k];
-            if (sizeof(T) == 2) gq = bf2f(f2bf(gq));
-            const float dz = gq * dsc[k] * act_bwd(u, act);
-            s[k] += dz;
-            t[k] += dz * xh;
+            const float2 ms = stats[(size_t)n * C + c0 + k];
+            xa[k] = ms.y; xb[k] = -ms.x * ms.y;          // xhat = raw*xa + xb
+            gam[k] = gamma[c0 + k]; bet[k] = beta[c0 + k];
+            dsc[k] = drop_scale(seed, site, n, c0 + k, drop_p);
+        }
+        const size_t img = (size_t)n * Hp * Wp;
+        const T* rbase = raw + img * ldc_raw + coff_raw + c0;
+        T* Gbase = G + img * ldc_G + coff_G + c0;
+        int q = q0 + m.px;
+        int y = q / W, x = q - y * W;
+        for (; q < q1; q += m.ppi) {
+            float acc[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+            fold_read8<T>(g1 + coff_g1 + c0, n, y, x, H, W, ldc_g1, pm, fold1, acc);
+            if (g2) fold_read8<T>(g2 + coff_g2 + c0, n, y, x, H, W, ldc_g2, pm, fold2, acc);
+            const size_t pix = (size_t)(y + 1) * Wp + x + 1;
+            Vec8<T> go;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) go.v[k] = acc[k];
+            go.store(Gbase + pix * ldc_G);
+            Vec8<T> r;
+            r.load(rbase + pix * ldc_raw);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                // use the value as stored (bf16-rounded in bf16 mode) so that pass 2 sees the same G
+                const float xh = fmaf(r.v[k], xa[k], xb[k]);
+                const float u = fmaf(xh, gam[k], bet[k]);
+                float gq = go.v[k];
+                if (sizeof(T) == 2) gq = bf2f(f2bf(gq));
+                const float dz = gq * dsc[k] * act_bwd(u, act);
+                s[k] += dz;
+                t[k] = fmaf(dz, xh, t[k]);
+            }
+            x += m.ppi;
+            while (x >= W) { x -= W; ++y; }
         }
     }
-    block_sum8(s, red);
-    block_sum8(t, red);
-    if (threadIdx.x < 8) {
-        const int k = threadIdx.x;
-        float a = 0.f, b = 0.f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) if (j == k) { a = s[j]; b = t[j]; }
-        S[(size_t)n * C + c0 + k] = make_float2(a, b);
+    for (int k = 0; k < 8; ++k) { red[threadIdx.x * 16 + k] = s[k]; red[threadIdx.x * 16 + 8 + k] = t[k]; }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < m.groups * 16; idx += kThreads) {
+        const int cg = idx >> 4, k = idx & 15;
+        float a = 0.f;
+        for (int p = 0; p < m.ppi; ++p) a += red[(p * m.groups + cg) * 16 + k];
+        atomicAdd(S + ((size_t)n * C + cg * 8 + (k & 7)) * 2 + (k >> 3), a);
     }
 }
 
@@ -224,38 +308,53 @@ __global__ __launch_bounds__(256) void k_inact_bwd_reduce(const T* g1, const T* 
 // the flattened dgrad / wgrad convolutions directly).
 template <typename T>
 __global__ __launch_bounds__(256) void k_inact_bwd_apply(const T* G, const T* raw, const float2* stats, const float* gamma, const float* beta,
-                                  const float2* S, T* draw, int B, int H, int W, int C, int ldc_G, int coff_G, int ldc_raw,
-                                  int coff_raw, int ldc_d, int coff_d, int act, uint32_t site, uint32_t seed, float drop_p) {
-    const int Hp = H + 2, Wp = W + 2, groups = C >> 3;
-    const int row = blockIdx.x;
-    const int n = row / Hp, y = row % Hp;
-    const int item = blockIdx.y * kThreads + threadIdx.x;
-    if (item >= Wp * groups) return;
-    const int x = item / groups, cg = item - x * groups, c0 = cg * 8;
-    const size_t pix = (size_t)row * Wp + x;
-    T* d = draw + pix * ldc_d + coff_d + c0;
-    Vec8<T> o;
-    if (y == 0 || y == Hp - 1 || x == 0 || x == Wp - 1) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) o.v[k] = 0.f;
-        o.store(d);
-        return;
-    }
-    Vec8<T> g, r;
-    g.load(G + pix * ldc_G + coff_G + c0);
-    r.load(raw + pix * ldc_raw + coff_raw + c0);
+                                  const float2* S, T* draw, int H, int W, int C, int ldc_G, int coff_G, int ldc_raw,
+                                  int coff_raw, int ldc_d, int coff_d, int act, uint32_t site, uint32_t seed, float drop_p,
+                                  int p_per_block) {
+    const CgMap m(C);
+    if (!m.active) return;
+    const int n = blockIdx.y, Hp = H + 2, Wp = W + 2, c0 = m.cg * 8;
+    const int p0 = blockIdx.x * p_per_block, p1 = min(Hp * Wp, p0 + p_per_block);
     const float inv = 1.f / (float)(H * W);
+    float xa[8], xb[8], gam[8], bet[8], dsc[8], k0[8], k1[8], k2[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const float2 ms = stats[(size_t)n * C + c0 + k];
         const float2 ss = S[(size_t)n * C + c0 + k];
-        const float gm = gamma[c0 + k];
-        const float xh = (r.v[k] - ms.x) * ms.y;
-        const float u = xh * gm + beta[c0 + k];
-        const float dz = g.v[k] * drop_scale(seed, site, n, c0 + k, drop_p) * act_bwd(u, act);
-        o.v[k] = gm * ms.y * (dz - ss.x * inv - xh * ss.y * inv);
+        xa[k] = ms.y; xb[k] = -ms.x * ms.y;
+        gam[k] = gamma[c0 + k]; bet[k] = beta[c0 + k];
+        dsc[k] = drop_scale(seed, site, n, c0 + k, drop_p);
+        k0[k] = gam[k] * ms.y;                            // out = k0*(dz - k1 - xh*k2)
+        k1[k] = ss.x * inv;
+        k2[k] = ss.y * inv;
     }
-    o.store(d);
+    const size_t img = (size_t)n * Hp * Wp;
+    const T* Gbase = G + img * ldc_G + coff_G + c0;
+    const T* rbase = raw + img * ldc_raw + coff_raw + c0;
+    T* dbase = draw + img * ldc_d + coff_d + c0;
+    int p = p0 + m.px;
+    int y = p / Wp, x = p - y * Wp;
+    for (; p < p1; p += m.ppi) {
+        Vec8<T> o;
+        if (y == 0 || y == Hp - 1 || x == 0 || x == Wp - 1) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o.v[k] = 0.f;
+        } else {
+            Vec8<T> g, r;
+            g.load(Gbase + (size_t)p * ldc_G);
+            r.load(rbase + (size_t)p * ldc_raw);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float xh = fmaf(r.v[k], xa[k], xb[k]);
+                const float u = fmaf(xh, gam[k], bet[k]);
+                const float dz = g.v[k] * dsc[k] * act_bwd(u, act);
+                o.v[k] = k0[k] * (dz - k1[k] - xh * k2[k]);
+            }
+        }
+        o.store(dbase + (size_t)p * ldc_d);
+        x += m.ppi;
+        while (x >= Wp) { x -= Wp; ++y; }
+    }
 }
 
 // ------------------------------------------------------------------ AFFINE_GRAD: dgamma += sum_n S2, dbeta += sum_n S1
@@ -497,6 +596,19 @@ inline bool vec_ok(const void* p, int ldc, int coff, int C, int dtype) {
            (((uintptr_t)p) % (8 * esz)) == 0;
 }
 inline bool vec_ok_opt(const void* p, int ldc, int coff, int C, int dtype) { return p == nullptr || vec_ok(p, ldc, coff, C, dtype); }
+// cg kernels: pixels per block so that the launch has ~2048 blocks (8 per CU) but every thread still walks >= 4 pixels
+inline int cg_pixels_per_block(int npix, int B, int C, int* chunks_out) {
+    const int ppi = kThreads / (C >> 3);
+    int chunks = (2048 + B - 1) / B;
+    const int max_chunks = (npix + ppi * 4 - 1) / (ppi * 4);
+    if (chunks > max_chunks) chunks = max_chunks;
+    if (chunks < 1) chunks = 1;
+    int per = (npix + chunks - 1) / chunks;
+    per = (per + ppi - 1) / ppi * ppi;       // whole iterations: keeps a block's pixel range a multiple of the stride
+    *chunks_out = (npix + per - 1) / per;
+    return per;
+}
+inline bool cg_ok(int C, int B) { return C >= 8 && (C >> 3) <= kThreads && B > 0 && B < 65536; }
 
 }  // namespace
 
@@ -517,10 +629,23 @@ int fnet_op_pack_input(const FnetOp& op, hipStream_t st) {
     return FNET_OK;
 }
 
-// IN_STATS  i: 0 B,1 H,2 W,3 C,4 ldc,5 coff; f: 0 eps; p: 0 raw, 1 stats float2[B][C] = (mean, rstd)
+// IN_STATS  i: 0 B,1 H,2 W,3 C,4 ldc,5 coff,6 scratch floats; f: 0 eps; p: 0 raw, 1 stats float2[B][C] = (mean, rstd), 2 scratch|0
 int fnet_op_in_stats(const FnetOp& op, hipStream_t st) {
     const int B = op.i[0], H = op.i[1], W = op.i[2], C = op.i[3];
     FNET_CHECK_ARG(B > 0 && H > 0 && W > 0 && vec_ok((void*)op.p[0], op.i[4], op.i[5], C, op.dtype) && op.p[1]);
+    if (op.dtype == FNET_BF16 && cg_ok(C, B) && op.p[2]) {
+        // one coalesced pass into per-block partials + ordered finalize (bf16 plans; p[2] = scratch of i[6] floats);
+        // fp32 plans, or no scratch, keep the exact two-pass kernel below
+        int chunks;
+        const int per = cg_pixels_per_block(H * W, B, C, &chunks);
+        FNET_CHECK_ARG((long long)B * chunks * C * 2 <= (long long)op.i[6]);
+        hipLaunchKernelGGL(k_in_stats_part<bf16_t>, dim3(chunks, B), dim3(kThreads), 0, st, (const bf16_t*)op.p[0], (float*)op.p[2], H, W, C,
+                           op.i[4], op.i[5], per);
+        hipLaunchKernelGGL(k_in_finalize, dim3((B * C + kThreads - 1) / kThreads), dim3(kThreads), 0, st, (const float2*)op.p[2],
+                           (float2*)op.p[1], B, C, chunks, 1.f / (float)(H * W), op.f[0]);
+        FNET_LAUNCH_CHECK();
+        return FNET_OK;
+    }
     DISPATCH_T(op.dtype, hipLaunchKernelGGL(k_in_stats<T>, dim3(B * (C / 8)), dim3(kThreads), 0, st, (const T*)op.p[0],
                                             (float2*)op.p[1], B, H, W, C, op.i[4], op.i[5], op.f[0]));
     FNET_LAUNCH_CHECK();
@@ -537,19 +662,21 @@ int fnet_op_apply(const FnetOp& op, hipStream_t st) {
     FNET_CHECK_ARG(vec_ok((void*)op.p[5], op.i[8], op.i[9], C, op.dtype));
     FNET_CHECK_ARG(op.i[10] >= 0 && op.i[10] <= 4 && op.i[11] >= 0 && op.i[11] <= 3);
     FNET_CHECK_ARG(op.p[1] == 0 || (op.p[2] != 0 && op.p[3] != 0));
-    FNET_CHECK_ARG(op.f[0] >= 0.f && op.f[0] < 1.f);
-    DISPATCH_T(op.dtype, hipLaunchKernelGGL(k_apply<T>, row_grid(B * (H + 2), (W + 2) * (C / 8)), dim3(kThreads), 0, st,
+    FNET_CHECK_ARG(op.f[0] >= 0.f && op.f[0] < 1.f && cg_ok(C, B));
+    int chunks;
+    const int per = cg_pixels_per_block((H + 2) * (W + 2), B, C, &chunks);
+    DISPATCH_T(op.dtype, hipLaunchKernelGGL(k_apply<T>, dim3(chunks, B), dim3(kThreads), 0, st,
                                             (const T*)op.p[0], (const float2*)op.p[1], (const float*)op.p[2],
-                                            (const float*)op.p[3], (const T*)op.p[4], (T*)op.p[5], B, H, W, C, op.i[4],
+                                            (const float*)op.p[3], (const T*)op.p[4], (T*)op.p[5], H, W, C, op.i[4],
                                             op.i[5], op.i[6], op.i[7], op.i[8], op.i[9], op.i[10], op.i[11],
-                                            (uint32_t)op.i[12], (uint32_t)op.i[13], op.f[0]));
+                                            (uint32_t)op.i[12], (uint32_t)op.i[13], op.f[0], per));
     FNET_LAUNCH_CHECK();
     return FNET_OK;
 }
 
 // INACT_BWD_REDUCE  i: 0 B,1 H,2 W,3 C,4 ldc_g1,5 coff_g1,6 ldc_g2,7 coff_g2,8 ldc_raw,9 coff_raw,10 ldc_G,11 coff_G,
 //                      12 fold1,13 fold2,14 act,15 pm,16 drop site,17 seed; f: 0 drop_p
-//                   p: 0 g1,1 g2|0,2 raw,3 stats,4 gamma,5 beta,6 G out,7 S out float2[B][C]
+//                   p: 0 g1,1 g2|0,2 raw,3 stats,4 gamma,5 beta,6 G out,7 S float2[B][C] (+=: the plan zeroes it first)
 int fnet_op_inact_bwd_reduce(const FnetOp& op, hipStream_t st) {
     const int B = op.i[0], H = op.i[1], W = op.i[2], C = op.i[3];
     FNET_CHECK_ARG(B > 0 && H >= 2 && W >= 2);
@@ -557,13 +684,15 @@ int fnet_op_inact_bwd_reduce(const FnetOp& op, hipStream_t st) {
     FNET_CHECK_ARG(vec_ok_opt((void*)op.p[1], op.i[6], op.i[7], C, op.dtype));
     FNET_CHECK_ARG(vec_ok((void*)op.p[2], op.i[8], op.i[9], C, op.dtype));
     FNET_CHECK_ARG(vec_ok((void*)op.p[6], op.i[10], op.i[11], C, op.dtype));
-    FNET_CHECK_ARG(op.p[3] && op.p[4] && op.p[5] && op.p[7]);
+    FNET_CHECK_ARG(op.p[3] && op.p[4] && op.p[5] && op.p[7] && cg_ok(C, B));
+    int chunks;
+    const int per = cg_pixels_per_block(H * W, B, C, &chunks);
     DISPATCH_T(op.dtype,
-               hipLaunchKernelGGL(k_inact_bwd_reduce<T>, dim3(B * (C / 8)), dim3(kThreads), 0, st, (const T*)op.p[0],
+               hipLaunchKernelGGL(k_inact_bwd_reduce<T>, dim3(chunks, B), dim3(kThreads), 0, st, (const T*)op.p[0],
                                   (const T*)op.p[1], (const T*)op.p[2], (const float2*)op.p[3], (const float*)op.p[4],
-                                  (const float*)op.p[5], (T*)op.p[6], (float2*)op.p[7], B, H, W, C, op.i[4], op.i[5],
+                                  (const float*)op.p[5], (T*)op.p[6], (float*)op.p[7], H, W, C, op.i[4], op.i[5],
                                   op.i[6], op.i[7], op.i[8], op.i[9], op.i[10], op.i[11], op.i[12], op.i[13], op.i[14],
-                                  op.i[15], (uint32_t)op.i[16], (uint32_t)op.i[17], op.f[0]));
+                                  op.i[15], (uint32_t)op.i[16], (uint32_t)op.i[17], op.f[0], per));
     FNET_LAUNCH_CHECK();
     return FNET_OK;
 }
@@ -576,12 +705,14 @@ int fnet_op_inact_bwd_apply(const FnetOp& op, hipStream_t st) {
     FNET_CHECK_ARG(vec_ok((void*)op.p[0], op.i[4], op.i[5], C, op.dtype));
     FNET_CHECK_ARG(vec_ok((void*)op.p[1], op.i[6], op.i[7], C, op.dtype));
     FNET_CHECK_ARG(vec_ok((void*)op.p[6], op.i[8], op.i[9], C, op.dtype));
-    FNET_CHECK_ARG(op.p[2] && op.p[3] && op.p[4] && op.p[5]);
-    DISPATCH_T(op.dtype, hipLaunchKernelGGL(k_inact_bwd_apply<T>, row_grid(B * (H + 2), (W + 2) * (C / 8)), dim3(kThreads), 0,
+    FNET_CHECK_ARG(op.p[2] && op.p[3] && op.p[4] && op.p[5] && cg_ok(C, B));
+    int chunks;
+    const int per = cg_pixels_per_block((H + 2) * (W + 2), B, C, &chunks);
+    DISPATCH_T(op.dtype, hipLaunchKernelGGL(k_inact_bwd_apply<T>, dim3(chunks, B), dim3(kThreads), 0,
                                             st, (const T*)op.p[0], (const T*)op.p[1], (const float2*)op.p[2],
                                             (const float*)op.p[3], (const float*)op.p[4], (const float2*)op.p[5],
-                                            (T*)op.p[6], B, H, W, C, op.i[4], op.i[5], op.i[6], op.i[7], op.i[8], op.i[9],
-                                            op.i[10], (uint32_t)op.i[11], (uint32_t)op.i[12], op.f[0]));
+                                            (T*)op.p[6], H, W, C, op.i[4], op.i[5], op.i[6], op.i[7], op.i[8], op.i[9],
+                                            op.i[10], (uint32_t)op.i[11], (uint32_t)op.i[12], op.f[0], per));
     FNET_LAUNCH_CHECK();
     return FNET_OK;
 }

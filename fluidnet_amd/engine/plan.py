@@ -216,6 +216,9 @@ class PlanBuilder:
         self.n_params_padded = off
         self.params = self.new_buf("params_flat", (off,), "f32", external=True)
         self.grads = self.new_buf("grads_flat", (off,), "f32", external=True)
+        # per-block (sum, sumsq) partials of the one-pass InstanceNorm statistics: [B][chunks <= ceil(2048/B)][C][2]
+        cmax = cfg.base_channels * 2 ** cfg.depth
+        self.stats_scratch = self.new_buf("stats_scratch", (B * ((2048 + B - 1) // B) * cmax * 2,), "f32")
         self.convs: "OrderedDict[str, dict]" = OrderedDict()
         for k, s in self.shapes.items():
             if len(s) == 4 and s[2] == 3:
@@ -282,7 +285,9 @@ class PlanBuilder:
     def conv_flops(self, name: str, H: int, W: int) -> float:
         """2*MAC of the real convolution `name` evaluated on an HxW input grid (real channels; stride-2 convs count
         their H/2 x W/2 outputs) -- SURVEY.md section 8d's convention."""
-        c = self.convs[name.split("/")[0]]
+        c = self.convs.get(name.split("/")[0])
+        if c is None:                       # not a layer of the network (unit tests drive e_conv directly)
+            return 0.0
         fl = 2.0 * self.B * H * W * 9 * c["Cin"] * c["Cout"]
         return fl / 4 if name.split("/")[0].endswith(".down") else fl
 
@@ -303,7 +308,8 @@ class PlanBuilder:
         ops[-1].flops = self.conv_flops(conv, src.H, src.W)
 
     def e_stats(self, ops, raw: PV, st: Buf):
-        self.op(ops, "IN_STATS", [self.B, raw.H, raw.W, raw.C, raw.ldc, raw.coff], f=[1e-5], p=[raw.ref, Ref(st)])
+        sc = self.stats_scratch
+        self.op(ops, "IN_STATS", [self.B, raw.H, raw.W, raw.C, raw.ldc, raw.coff, sc.numel], f=[1e-5], p=[raw.ref, Ref(st), Ref(sc)])
 
     def e_apply(self, ops, u: Unit):
         raw = PV(u.raw, u.out.C)
@@ -408,6 +414,7 @@ class PlanBuilder:
         S = self.new_buf(f"S/{u.conv}/{len(self.bufs)}", (B, C, 2), "f32")
         g1 = srcs[0]
         g2 = srcs[1] if len(srcs) > 1 else None
+        self.emit_zero(ops, S)              # the reduce kernel adds its per-block partial sums into S
         self.op(ops, "INACT_BWD_REDUCE",
                 [B, H, W, C, g1.pv.ldc, g1.pv.coff, g2.pv.ldc if g2 else 8, g2.pv.coff if g2 else 0, C, 0, C, 0,
                  g1.fold, g2.fold if g2 else 0, self.act, self.pm, u.drop_site, self.seed],

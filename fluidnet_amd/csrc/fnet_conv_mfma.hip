@@ -27,21 +27,84 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 constexpr int kThreads = 256;
 constexpr int TM = 256;     // pixels per block
 constexpr int KC = 16;      // channels per LDS stage (= K of one MFMA)
-constexpr int PS = 48;      // LDS pitch of a 16-channel row, bytes
+constexpr int PS = 48;      // (weight-gradient kernel) LDS pitch of a 16-channel row, bytes
 
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void gbl_void_t;
+
+// ---- convolution, LDS-DMA double-buffered --------------------------------------------------------------------
+// LDS (one dynamic array): [weights buf0][weights buf1][input buf0][input buf1]; after the K loop the same memory holds
+// the bf16 output tile [256 px][TN co] for the coalesced store pass.
+//   input image  : RINP pixels (TM + 2Wp + 2 rounded up to 32) x 16 channels = 32 B per pixel, two 16-B slots
+//   weight image : 9*TN rows (tap, cout) x 16 channels = 32 B per row
+// Both images are filled by LDS-DMA (buffer_load/global_load ... lds: no VGPR round trip, no ds_write): one wave
+// instruction moves 64 x 16 B = 32 rows, landing linearly in LDS; the bank swizzle therefore lives in the per-lane
+// SOURCE address: row p keeps its two 16-B halves swapped when bit 3 of p is set, slot(p,h) = 2p + (h ^ ((p>>3)&1)),
+// which makes every ds_read_b128 fragment read (16 lanes = 16 consecutive rows, same half) hit 16 distinct slots.
+// The input goes through a buffer descriptor windowed on the tile's pixel run, so pixels before the start / past the
+// end of the tensor read as zero (the flattened-convolution semantics of the P-tensor layout, see fluidnet_hip.h).
+// Pipeline: barrier -> issue DMA of stage s+1 -> 9 taps x (2 + NT) fragment reads + 2*NT MFMAs on stage s.
+// MFMA orientation: A = weights (rows = cout), B = pixels, so D[cout][pixel] leaves 4 consecutive couts of one pixel in
+// each accumulator quad = one 8-B LDS store into the pixel-major output tile.
 template <int TN>
-__global__ __launch_bounds__(256) void k_conv3x3_mfma(const bf16_t* __restrict__ src, const bf16_t* __restrict__ Wk,
-                                                      const float* __restrict__ bias, bf16_t* __restrict__ dst, int Npix, int Wp,
-                                                      int Cin, int ldc_in, int coff_in, int Cout, int ldc_out, int coff_out) {
+__global__ __launch_bounds__(256, 2) void k_conv3x3_dma(const bf16_t* __restrict__ src, const bf16_t* __restrict__ Wk,
+                                                        const float* __restrict__ bias, bf16_t* __restrict__ dst, int Npix, int Wp,
+                                                        int Cin, int ldc_in, int coff_in, int Cout, int ldc_out, int coff_out,
+                                                        int n_mtiles, int n_ntiles, int rinp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NT = TN / 32;
-    const int rows_in = TM + 2 * Wp + 2;
-    unsigned char* lds_in = smem;
-    unsigned char* lds_w = smem + (size_t)rows_in * PS;  // rows_in*48 is a multiple of 16
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int WB = 9 * TN * 32;                 // weight image bytes
+    constexpr int NPW = 9 * TN / 32;                // weight DMA pieces per stage
+    const int IB = rinp * 32;                       // input image bytes
+    const int npi = rinp >> 5;                      // input DMA pieces per stage
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const long long f0 = (long long)blockIdx.x * TM;
-    const int n0 = blockIdx.y * TN;
+
+    // XCD-aware tile order: blocks with equal blockIdx % 8 share an L2; give each XCD a contiguous range of pixel tiles
+    // and run the cout tiles of one pixel tile back to back on it.
+    const int cpx = (n_mtiles + 7) >> 3;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int mt = xcd * cpx + j / n_ntiles;
+    const int nt = j - (j / n_ntiles) * n_ntiles;
+    if (mt >= n_mtiles) return;
+    const long long f0 = (long long)mt * TM;
+    const int n0 = nt * TN;
+
+    // input window descriptor
+    const long long gbase = f0 - Wp - 1;
+    const long long wpix = gbase > 0 ? gbase : 0;
+    long long wbytes = ((long long)Npix - wpix) * ldc_in * 2;
+    const long long wmax = (long long)(rinp + 1) * ldc_in * 2;
+    if (wbytes > wmax) wbytes = wmax;
+    const __amdgpu_buffer_rsrc_t rs =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(src + (size_t)wpix * ldc_in), 0, (int)wbytes, 0x00020000);
+    const int swz = (lane >> 4) & 1;                // bit 3 of the row a DMA lane fills (row = 32*piece + lane/2)
+    const int dh = (lane & 1) ^ swz;                // channel half this lane fetches
+    const int in_lane_off = (int)(((long long)(lane >> 1) + (gbase - wpix)) * ldc_in + coff_in + dh * 8) * 2;
+    const int in_piece_stride = 32 * ldc_in * 2;
+    // weight source: row = 32*piece + lane/2 -> (tap, col)
+    const int wrow = lane >> 1;
+
+    auto issue = [&](int s, int buf) {
+        const int c0 = s * KC;
+        unsigned char* wdst = smem + buf * WB;
+        unsigned char* idst = smem + 2 * WB + buf * IB;
+        for (int q = wave; q < npi + NPW; q += 4) {
+            if (q < npi) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(idst + q * 1024), 16, in_lane_off + q * in_piece_stride + c0 * 2,
+                                                         0, 0, 0);
+            } else {
+                const int qw = q - npi;
+                const int row = qw * 32 + wrow;
+                const int t = row / TN;
+                int co = n0 + (row - t * TN);
+                co = co < Cout ? co : Cout - 1;
+                const bf16_t* g = Wk + ((size_t)t * Cout + co) * Cin + c0 + dh * 8;
+                __builtin_amdgcn_global_load_lds((gbl_void_t*)g, (lds_void_t*)(wdst + qw * 1024), 16, 0, 0);
+            }
+        }
+    };
 
     f32x16 acc[2][NT];
 #pragma unroll
@@ -51,58 +114,75 @@ __global__ __launch_bounds__(256) void k_conv3x3_mfma(const bf16_t* __restrict__
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[ms][ns][i] = 0.f;
 
-    const long long gbase = f0 - Wp - 1;
-    for (int c0 = 0; c0 < Cin; c0 += KC) {
-        // stage the input run: 2 x 16-B pieces per pixel
-        for (int p = tid; p < rows_in * 2; p += kThreads) {
-            const int row = p >> 1, half = p & 1;
-            const long long g = gbase + row;
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (g >= 0 && g < Npix) v = *reinterpret_cast<const uint4*>(src + (size_t)g * ldc_in + coff_in + c0 + half * 8);
-            *reinterpret_cast<uint4*>(lds_in + row * PS + half * 16) = v;
+    // fragment read addresses (bytes, buffer 0): 9 taps x 2 pixel sub-tiles; weights: one lane base + immediates
+    unsigned xaddr[9][2];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int ms = 0; ms < 2; ++ms) {
+            const int p = wave * 64 + ms * 32 + r + (t / 3) * Wp + (t % 3);
+            xaddr[t][ms] = 2 * WB + (unsigned)(2 * p + (h ^ ((p >> 3) & 1))) * 16;
         }
-        // stage the weight slab [9][TN][16]
-        for (int p = tid; p < 9 * TN * 2; p += kThreads) {
-            const int row = p >> 1, half = p & 1;
-            const int t = row / TN, col = row - t * TN;
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (n0 + col < Cout) v = *reinterpret_cast<const uint4*>(Wk + ((size_t)t * Cout + n0 + col) * Cin + c0 + half * 8);
-            *reinterpret_cast<uint4*>(lds_w + row * PS + half * 16) = v;
-        }
-        __syncthreads();
+    const unsigned waddr = (unsigned)(2 * r + (h ^ ((r >> 3) & 1))) * 16;
+
+    const int nst = Cin / KC;
+    issue(0, 0);
+    for (int s = 0; s < nst; ++s) {
+        __syncthreads();  // stage s has landed (vmcnt(0) + barrier); every wave is done with the other buffer
+        if (s + 1 < nst) issue(s + 1, (s + 1) & 1);
+        const unsigned ib = (s & 1) ? (unsigned)IB : 0u;
+        const unsigned wb = (s & 1) ? (unsigned)WB : 0u;
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-            const int toff = (t / 3) * Wp + (t % 3);
-            bf16x8 a[2], b[NT];
+            bf16x8 xb[2], wa[NT];
 #pragma unroll
-            for (int ms = 0; ms < 2; ++ms)
-                a[ms] = *reinterpret_cast<const bf16x8*>(lds_in + (wave * 64 + ms * 32 + r + toff) * PS + h * 16);
+            for (int ms = 0; ms < 2; ++ms) xb[ms] = *reinterpret_cast<const bf16x8*>(smem + xaddr[t][ms] + ib);
 #pragma unroll
-            for (int ns = 0; ns < NT; ++ns)
-                b[ns] = *reinterpret_cast<const bf16x8*>(lds_w + (t * TN + ns * 32 + r) * PS + h * 16);
+            for (int ns = 0; ns < NT; ++ns) wa[ns] = *reinterpret_cast<const bf16x8*>(smem + waddr + wb + (t * TN + ns * 32) * 32);
 #pragma unroll
             for (int ms = 0; ms < 2; ++ms)
 #pragma unroll
                 for (int ns = 0; ns < NT; ++ns)
-                    acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ms], b[ns], acc[ms][ns], 0, 0, 0);
+                    acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ns], xb[ms], acc[ms][ns], 0, 0, 0);
         }
-        __syncthreads();
     }
+    __syncthreads();  // all fragment reads done: reuse LDS for the output tile
 
-    // epilogue: C/D map of 32x32 MFMA: col = lane&31, row = (i&3) + 8*(i>>2) + 4*(lane>>5)
+    // D[row = cout][col = pixel]: lane (r, h) holds pixel r, couts (i&3) + 8*(i>>2) + 4*h
+    constexpr int PO = TN * 2 + 16;  // output tile pitch (bytes)
 #pragma unroll
-    for (int ns = 0; ns < NT; ++ns) {
-        const int co = n0 + ns * 32 + r;
-        if (co >= Cout) continue;
-        const float bv = bias ? bias[co] : 0.f;
+    for (int ns = 0; ns < NT; ++ns)
 #pragma unroll
-        for (int ms = 0; ms < 2; ++ms)
+        for (int q = 0; q < 4; ++q) {
+            const int col = ns * 32 + 8 * q + 4 * h;
+            float bv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (bias) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
-                const long long f = f0 + wave * 64 + ms * 32 + row;
-                if (f < Npix) dst[(size_t)f * ldc_out + coff_out + co] = f2bf(acc[ms][ns][i] + bv);
+                for (int k = 0; k < 4; ++k) bv[k] = (n0 + col + k < Cout) ? bias[n0 + col + k] : 0.f;
             }
+#pragma unroll
+            for (int ms = 0; ms < 2; ++ms) {
+                const int px = wave * 64 + ms * 32 + r;
+                uint2 v;
+                v.x = (uint32_t)f2bf(acc[ms][ns][4 * q + 0] + bv[0]) | ((uint32_t)f2bf(acc[ms][ns][4 * q + 1] + bv[1]) << 16);
+                v.y = (uint32_t)f2bf(acc[ms][ns][4 * q + 2] + bv[2]) | ((uint32_t)f2bf(acc[ms][ns][4 * q + 3] + bv[3]) << 16);
+                *reinterpret_cast<uint2*>(smem + px * PO + col * 2) = v;
+            }
+        }
+    __syncthreads();
+    constexpr int CH = TN / 8;             // 16-B chunks per pixel
+    constexpr int PPI = kThreads / CH;     // pixels per pass
+    const int chunk = tid % CH, px0 = tid / CH;
+    if (n0 + chunk * 8 < Cout) {
+#pragma unroll
+        for (int k = 0; k < TM / PPI; ++k) {
+            const int px = px0 + k * PPI;
+            const long long f = f0 + px;
+            if (f < Npix) {
+                const uint4 v = *reinterpret_cast<const uint4*>(smem + px * PO + chunk * 16);
+                *reinterpret_cast<uint4*>(dst + (size_t)f * ldc_out + coff_out + n0 + chunk * 8) = v;
+            }
+        }
     }
 }
 
@@ -210,25 +290,32 @@ int set_lds_limit(K kernel, size_t bytes) {
 int fnet_conv3x3_mfma(const FnetOp& op, hipStream_t st) {
     const int Npix = op.i[0], Wp = op.i[1], Cin = op.i[2], Cout = op.i[5];
     FNET_CHECK_ARG(op.dtype == FNET_BF16);
-    FNET_CHECK_ARG(Cin % KC == 0 && op.i[3] % 8 == 0 && op.i[4] % 8 == 0);
+    FNET_CHECK_ARG(Npix > 0 && Wp >= 3 && Cin % KC == 0 && Cout % 8 == 0 && Cout > 0);
+    FNET_CHECK_ARG(op.i[3] % 8 == 0 && op.i[4] % 8 == 0 && op.i[6] % 8 == 0 && op.i[7] % 8 == 0);
+    FNET_CHECK_ARG(op.i[4] + Cin <= op.i[3] && op.i[7] + Cout <= op.i[6]);
+    FNET_CHECK_ARG(op.p[0] && op.p[1] && op.p[3] && (op.p[0] % 16) == 0 && (op.p[1] % 16) == 0 && (op.p[3] % 16) == 0);
     const int TN = Cout > 32 ? 64 : 32;
-    const size_t lds = (size_t)(TM + 2 * Wp + 2) * PS + (size_t)9 * TN * PS;
-    FNET_CHECK_ARG(lds <= 160 * 1024);
-    const dim3 grid((Npix + TM - 1) / TM, (Cout + TN - 1) / TN);
+    const int rinp = (TM + 2 * Wp + 2 + 31) / 32 * 32;
+    const size_t lds = 2 * ((size_t)rinp * 32 + (size_t)9 * TN * 32);
+    FNET_CHECK_ARG(lds <= 160 * 1024 && lds >= (size_t)TM * (TN * 2 + 16));
+    // the DMA window offsets are 32-bit
+    FNET_CHECK_ARG((long long)(rinp + 2) * op.i[3] * 2 < (1ll << 30));
+    const int n_mtiles = (Npix + TM - 1) / TM, n_ntiles = (Cout + TN - 1) / TN;
+    const dim3 grid(8 * ((n_mtiles + 7) / 8) * n_ntiles);
     const bf16_t* src = (const bf16_t*)op.p[0];
     const bf16_t* Wk = (const bf16_t*)op.p[1];
     const float* bias = (const float*)op.p[2];
     bf16_t* dst = (bf16_t*)op.p[3];
     if (TN == 64) {
-        int rc = set_lds_limit(k_conv3x3_mfma<64>, lds);
+        int rc = set_lds_limit(k_conv3x3_dma<64>, lds);
         if (rc) return rc;
-        hipLaunchKernelGGL(k_conv3x3_mfma<64>, grid, dim3(kThreads), lds, st, src, Wk, bias, dst, Npix, Wp, Cin, op.i[3], op.i[4], Cout,
-                           op.i[6], op.i[7]);
+        hipLaunchKernelGGL(k_conv3x3_dma<64>, grid, dim3(kThreads), lds, st, src, Wk, bias, dst, Npix, Wp, Cin, op.i[3], op.i[4], Cout,
+                           op.i[6], op.i[7], n_mtiles, n_ntiles, rinp);
     } else {
-        int rc = set_lds_limit(k_conv3x3_mfma<32>, lds);
+        int rc = set_lds_limit(k_conv3x3_dma<32>, lds);
         if (rc) return rc;
-        hipLaunchKernelGGL(k_conv3x3_mfma<32>, grid, dim3(kThreads), lds, st, src, Wk, bias, dst, Npix, Wp, Cin, op.i[3], op.i[4], Cout,
-                           op.i[6], op.i[7]);
+        hipLaunchKernelGGL(k_conv3x3_dma<32>, grid, dim3(kThreads), lds, st, src, Wk, bias, dst, Npix, Wp, Cin, op.i[3], op.i[4], Cout,
+                           op.i[6], op.i[7], n_mtiles, n_ntiles, rinp);
     }
     FNET_LAUNCH_CHECK();
     return FNET_OK;

@@ -240,7 +240,7 @@ __device__ __forceinline__ void fold_read8(const T* g, int n, int y, int x, int 
 // block's partial sums into S (zeroed by the plan before this op).
 template <typename T>
 __global__ __launch_bounds__(256) void k_inact_bwd_reduce(const T* g1, const T* g2, const T* raw, const float2* stats, const float* gamma,
-                                   const float* beta, T* G, float* S, int H, int W, int C, int ldc_g1,
+                                   const float* beta, T* G, float* S, float* dgamma, float* dbeta, int H, int W, int C, int ldc_g1,
                                    int coff_g1, int ldc_g2, int coff_g2, int ldc_raw, int coff_raw, int ldc_G, int coff_G,
                                    int fold1, int fold2, int act, int pm, uint32_t site, uint32_t seed, float drop_p, int q_per_block) {
     __shared__ float red[kThreads * 16];
@@ -299,7 +299,10 @@ __global__ __launch_bounds__(256) void k_inact_bwd_reduce(const T* g1, const T* 
         const int cg = idx >> 4, k = idx & 15;
         float a = 0.f;
         for (int p = 0; p < m.ppi; ++p) a += red[(p * m.groups + cg) * 16 + k];
-        atomicAdd(S + ((size_t)n * C + cg * 8 + (k & 7)) * 2 + (k >> 3), a);
+        const int c = cg * 8 + (k & 7);
+        atomicAdd(S + ((size_t)n * C + c) * 2 + (k >> 3), a);
+        // affine gradients: dbeta[c] += sum_n S1, dgamma[c] += sum_n S2  (ml/models/unet.py:22-23 InstanceNorm2d(affine=True))
+        if (dgamma) atomicAdd((k >> 3) ? dgamma + c : dbeta + c, a);
     }
 }
 
@@ -676,7 +679,8 @@ int fnet_op_apply(const FnetOp& op, hipStream_t st) {
 
 // INACT_BWD_REDUCE  i: 0 B,1 H,2 W,3 C,4 ldc_g1,5 coff_g1,6 ldc_g2,7 coff_g2,8 ldc_raw,9 coff_raw,10 ldc_G,11 coff_G,
 //                      12 fold1,13 fold2,14 act,15 pm,16 drop site,17 seed; f: 0 drop_p
-//                   p: 0 g1,1 g2|0,2 raw,3 stats,4 gamma,5 beta,6 G out,7 S float2[B][C] (+=: the plan zeroes it first)
+//                   p: 0 g1,1 g2|0,2 raw,3 stats,4 gamma,5 beta,6 G out,7 S float2[B][C] (+=: the plan zeroes it first),
+//                      8 dgamma|0 (+=), 9 dbeta|0 (+=)
 int fnet_op_inact_bwd_reduce(const FnetOp& op, hipStream_t st) {
     const int B = op.i[0], H = op.i[1], W = op.i[2], C = op.i[3];
     FNET_CHECK_ARG(B > 0 && H >= 2 && W >= 2);
@@ -684,13 +688,13 @@ int fnet_op_inact_bwd_reduce(const FnetOp& op, hipStream_t st) {
     FNET_CHECK_ARG(vec_ok_opt((void*)op.p[1], op.i[6], op.i[7], C, op.dtype));
     FNET_CHECK_ARG(vec_ok((void*)op.p[2], op.i[8], op.i[9], C, op.dtype));
     FNET_CHECK_ARG(vec_ok((void*)op.p[6], op.i[10], op.i[11], C, op.dtype));
-    FNET_CHECK_ARG(op.p[3] && op.p[4] && op.p[5] && op.p[7] && cg_ok(C, B));
+    FNET_CHECK_ARG(op.p[3] && op.p[4] && op.p[5] && op.p[7] && cg_ok(C, B) && ((op.p[8] == 0) == (op.p[9] == 0)));
     int chunks;
     const int per = cg_pixels_per_block(H * W, B, C, &chunks);
     DISPATCH_T(op.dtype,
                hipLaunchKernelGGL(k_inact_bwd_reduce<T>, dim3(chunks, B), dim3(kThreads), 0, st, (const T*)op.p[0],
                                   (const T*)op.p[1], (const T*)op.p[2], (const float2*)op.p[3], (const float*)op.p[4],
-                                  (const float*)op.p[5], (T*)op.p[6], (float*)op.p[7], H, W, C, op.i[4], op.i[5],
+                                  (const float*)op.p[5], (T*)op.p[6], (float*)op.p[7], (float*)op.p[8], (float*)op.p[9], H, W, C, op.i[4], op.i[5],
                                   op.i[6], op.i[7], op.i[8], op.i[9], op.i[10], op.i[11], op.i[12], op.i[13], op.i[14],
                                   op.i[15], (uint32_t)op.i[16], (uint32_t)op.i[17], op.f[0], per));
     FNET_LAUNCH_CHECK();

@@ -205,6 +205,7 @@ class PlanBuilder:
         self.pm = rt.PAD[cfg.padding_mode]
         self.act = rt.ACT[cfg.act]
         self.bufs: List[Buf] = []
+        self.s_slab: Optional[Buf] = None
         self.pool: Dict[Tuple, List[Buf]] = {}
         self.shapes = unet_param_shapes(cfg)
         self.offsets: "OrderedDict[str, int]" = OrderedDict()
@@ -258,6 +259,14 @@ class PlanBuilder:
         assert b.rc >= 0, b.name
         if b.rc == 0:
             self.pool[(b.shape[1] - 2, b.shape[2] - 2, b.shape[3])].append(b)
+
+    def s_alloc(self, n: int) -> Ref:
+        """n floats of the S slab (per-(n,c) backward sums of the InstanceNorm adjoint)."""
+        if self.s_slab is None:
+            self.s_slab = self.new_buf(f"S_slab/{len(self.bufs)}", (0,), "f32")
+        off = self.s_slab.shape[0]
+        self.s_slab.shape = (off + (n + 63) // 64 * 64,)
+        return Ref(self.s_slab, off)
 
     def pref(self, name: str) -> Ref:
         return Ref(self.params, self.offsets[name])
@@ -411,23 +420,23 @@ class PlanBuilder:
         assert 1 <= len(srcs) <= 2
         B, H, W, C = self.B, u.out.H, u.out.W, u.out.C
         G = self.tmp(H, W, C)
-        S = self.new_buf(f"S/{u.conv}/{len(self.bufs)}", (B, C, 2), "f32")
+        S = self.s_alloc(B * C * 2)         # float2[B][C] in the S slab (zeroed once per backward pass: emit_backward)
         g1 = srcs[0]
         g2 = srcs[1] if len(srcs) > 1 else None
-        self.emit_zero(ops, S)              # the reduce kernel adds its per-block partial sums into S
         self.op(ops, "INACT_BWD_REDUCE",
                 [B, H, W, C, g1.pv.ldc, g1.pv.coff, g2.pv.ldc if g2 else 8, g2.pv.coff if g2 else 0, C, 0, C, 0,
                  g1.fold, g2.fold if g2 else 0, self.act, self.pm, u.drop_site, self.seed],
                 f=[u.drop_p],
                 p=[g1.pv.ref, g2.pv.ref if g2 else None, Ref(u.raw), Ref(u.st), self.pref(u.norm + ".weight"),
-                   self.pref(u.norm + ".bias"), Ref(G), Ref(S)], tag=u.conv)
+                   self.pref(u.norm + ".bias"), Ref(G), S], tag=u.conv)
         for s in srcs:
             self.release(s.pv.buf)
         draw = self.tmp(H, W, C)
         self.op(ops, "INACT_BWD_APPLY", [B, H, W, C, C, 0, C, 0, C, 0, self.act, u.drop_site, self.seed], f=[u.drop_p],
-                p=[Ref(G), Ref(u.raw), Ref(u.st), self.pref(u.norm + ".weight"), self.pref(u.norm + ".bias"), Ref(S), Ref(draw)],
+                p=[Ref(G), Ref(u.raw), Ref(u.st), self.pref(u.norm + ".weight"), self.pref(u.norm + ".bias"), S, Ref(draw)],
                 tag=u.conv)
-        self.op(ops, "AFFINE_GRAD", [B, C], p=[Ref(S), self.gref(u.norm + ".weight"), self.gref(u.norm + ".bias")], tag=u.norm)
+        # separate tiny kernel: adding dgamma/dbeta from every block of the reduce kernel (2048 adders per address) cost more
+        self.op(ops, "AFFINE_GRAD", [B, C], p=[S, self.gref(u.norm + ".weight"), self.gref(u.norm + ".bias")], tag=u.norm)
         self.e_wgrad(ops, u.xin, PV(draw, C), u.conv)
         dx = None
         if need_dx:
@@ -486,6 +495,9 @@ class PlanBuilder:
         """Adjoint of emit_forward.  Accumulates parameter gradients (dWk scratch for 3x3 weights, grads_flat for the
         rest); writes d(input) [B,dx_channels,H,W] fp32 into dx_out when given."""
         cfg, B, H, W = self.cfg, self.B, self.H, self.W
+        zero_at = len(ops)
+        self.s_slab = None                   # a fresh slab per backward pass: buffers already allocated never change size
+        s_begin = 0
         x = t.head_in
         G = self.tmp(H, W, x.C)
         self.op(ops, "HEAD_BWD", [B, H, W, x.C, x.ldc, x.coff, x.C, 0, cfg.out_channels, rt.OUTACT[cfg.output_activation]],
@@ -524,6 +536,10 @@ class PlanBuilder:
         if need_dx:
             self.op(ops, "UNPACK_GRAD", [B, H, W, 16, dx_channels, self.pm], p=[g.pv.ref, Ref(dx_out)], tag="dx")
             self.release(g.pv.buf)
+        if self.s_slab is not None and self.s_slab.shape[0] > s_begin:
+            nbytes = (self.s_slab.shape[0] - s_begin) * 4
+            z = OpRec(OPC["ZERO"], [nbytes & 0x7FFFFFFF, nbytes >> 31], [], [Ref(self.s_slab, s_begin)], self.dtype, "S_slab")
+            ops.insert(zero_at, z)
 
     # -------------------------------------------------------------------------------------------- weights / optimiser
     def emit_prep_weights(self, ops) -> None:

@@ -199,7 +199,11 @@ class Sim:
         raw = self.rd(r.p[2], C, lr_, cr)[:, 1:-1, 1:-1]
         u, xh = self._u(raw, r.p[3].buf.tensor, self.flat(r.p[4])[:C], self.flat(r.p[5])[:C])
         dz = g * self._drop(B, C, site, seed, r.f[0]) * act_bwd(u, act)
-        r.p[7].buf.tensor.copy_(torch.stack([dz.sum((1, 2)), (dz * xh).sum((1, 2))], -1))
+        S = torch.stack([dz.sum((1, 2)), (dz * xh).sum((1, 2))], -1)
+        self.flat(r.p[7])[: B * C * 2] += S.reshape(-1)
+        if len(r.p) > 8 and r.p[8] is not None:
+            self.flat(r.p[8])[:C] += S[:, :, 1].sum(0)
+            self.flat(r.p[9])[:C] += S[:, :, 0].sum(0)
 
     def op_INACT_BWD_APPLY(self, r):
         B, H, W, C, lG, cG, lr_, cr, ld, cd, act, site, seed = r.i[:13]
@@ -209,7 +213,7 @@ class Sim:
         gamma = self.flat(r.p[3])[:C]
         u, xh = self._u(raw, stats, gamma, self.flat(r.p[4])[:C])
         dz = g * self._drop(B, C, site, seed, r.f[0]) * act_bwd(u, act)
-        S = r.p[5].buf.tensor
+        S = self.flat(r.p[5])[: B * C * 2].view(B, C, 2)
         inv = 1.0 / (H * W)
         d = gamma * stats[:, None, None, :, 1] * (dz - S[:, None, None, :, 0] * inv - xh * S[:, None, None, :, 1] * inv)
         out = torch.zeros(B, H + 2, W + 2, C)
@@ -218,7 +222,7 @@ class Sim:
 
     def op_AFFINE_GRAD(self, r):
         B, C = r.i[:2]
-        S = r.p[0].buf.tensor
+        S = self.flat(r.p[0])[: B * C * 2].view(B, C, 2)
         self.flat(r.p[2])[:C] += S[:, :, 0].sum(0)
         self.flat(r.p[1])[:C] += S[:, :, 1].sum(0)
 

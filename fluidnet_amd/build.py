@@ -58,7 +58,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
     with ThreadPoolExecutor(max_workers=min(6, max(1, len(jobs)))) as ex:
         list(ex.map(run, jobs))
     if force or jobs or _stale(LIB, objs):
-        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs])
+        # -z defs: an unresolved kernel stub must fail the build here, not the dlopen on the GPU box
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-z,defs", "-o", LIB, *objs])
     return LIB
 
 

@@ -277,6 +277,165 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma(const bf16_t* __restrict__ s
     }
 }
 
+// ---- weight gradient, LDS-DMA double-buffered, 2-D pixel chunks, slab reduction ------------------------------------
+// K axis = interior pixels only (the ring of dout is zero by construction of every producer: INACT_BWD_APPLY, FOLD_SUM,
+// ZERO_INSERT), walked in chunks of 64 pixels shaped CH x CW (2 x 32 or 4 x 16) so that the source halo is
+// (CH+2) x (CW+2) <= 144 pixels whatever the image width.  Per stage the block DMA-loads NCO dout panels [64 px][32 co] and
+// NCI source panels [144 px][32 ci] (64-B rows, the layout ds_read_b64_tr_b16 reads conflict-free), double-buffered
+// exactly like the convolution.  Each wave keeps the nine 32x32 tap accumulators of one (co, ci) panel pair in
+// registers for its whole pixel range and finally writes them, with plain coalesced stores, as one 36-KB partial into
+// the slab; k_wgrad_reduce adds the partials into dWk.  (Accumulating with float atomics instead ran at the chip-wide
+// atomic rate: ~140 MB of adds per launch at 1.3 TB/s was a third of the kernel.)
+constexpr int WG_PX = 64;                 // pixels per chunk
+constexpr int WG_SROWS = 144;             // source rows staged per panel (>= (CH+2)*(CW+2))
+constexpr int WG_PART = 9 * 32 * 32;      // floats per wave partial
+
+// one stage of DMA for chunk c into LDS buffer `buf` (see k_wgrad_dma)
+template <int NCO, int NCI, int PPW>
+__device__ __forceinline__ void wg_issue(unsigned char* smem, const bf16_t* __restrict__ src, const bf16_t* __restrict__ dout, int c, int buf,
+                                         int wave, int H, int W, int ldc_in, int ldc_do, int log2cw, int cpi, int ncx,
+                                         const int (&p_off)[PPW], const int (&p_lds)[PPW], const int (&p_cyx)[PPW]) {
+    constexpr int DB = NCO * WG_PX * PANEL_ROW;
+    constexpr int SB = NCI * WG_SROWS * PANEL_ROW;
+    constexpr int STAGE = DB + SB;
+    constexpr int NPD = NCO * (WG_PX / 16);
+    constexpr int NP = NPD + NCI * (WG_SROWS / 16);
+    const int Hp = H + 2, Wp = W + 2;
+    const int CW = 1 << log2cw, CH = WG_PX >> log2cw;
+    const int n = c / cpi, rem = c - n * cpi;
+    const int cyi = rem / ncx, cxi = rem - cyi * ncx;
+    const int y0 = 1 + cyi * CH, x0 = 1 + cxi * CW;   // padded coordinates of the chunk origin
+    const size_t img = (size_t)n * Hp * Wp;
+    const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc((void*)(dout + img * ldc_do), 0, Hp * Wp * ldc_do * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rss = __builtin_amdgcn_make_buffer_rsrc((void*)(src + img * ldc_in), 0, Hp * Wp * ldc_in * 2, 0x00020000);
+    const int dbase = (y0 * Wp + x0) * ldc_do * 2;
+    const int sbase = ((y0 - 1) * Wp + x0 - 1) * ldc_in * 2;
+    unsigned char* base = smem + buf * STAGE;
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int pid = wave + 4 * i;
+        if (pid < NPD) {
+            const int cy = p_cyx[i] & 0xff, cx = p_cyx[i] >> 8;
+            const bool ok = (y0 + cy <= H) && (x0 + cx <= W);
+            const int off = ok ? p_off[i] + dbase : 0x7ffffff0;          // out of range -> the DMA writes zeros
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsd, (lds_void_t*)(base + p_lds[i]), 16, off, 0, 0, 0);
+        } else if (pid < NP) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rss, (lds_void_t*)(base + p_lds[i]), 16, p_off[i] + sbase, 0, 0, 0);
+        }
+    }
+}
+
+template <int NCO, int NCI>
+__global__ __launch_bounds__(256, 2) void k_wgrad_dma(const bf16_t* __restrict__ src, const bf16_t* __restrict__ dout,
+                                                      float* __restrict__ slab, int B, int H, int W, int ldc_in, int coff_in,
+                                                      int ldc_do, int coff_do, int log2cw, int chunks_per_block, int nchunks,
+                                                      int nparts, int n_ci_tiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int KS = 4 / (NCO * NCI);       // waves that share one (co,ci) panel pair and split the k-steps
+    constexpr int DB = NCO * WG_PX * PANEL_ROW;      // dout bytes per stage
+    constexpr int SB = NCI * WG_SROWS * PANEL_ROW;   // source bytes per stage
+    constexpr int STAGE = DB + SB;
+    constexpr int NPD = NCO * (WG_PX / 16);          // DMA pieces (16 rows x 64 B) per stage: dout
+    constexpr int NPSP = WG_SROWS / 16;              // ... per source panel
+    constexpr int NP = NPD + NCI * NPSP;
+    constexpr int PPW = (NP + 3) / 4;                // pieces per wave
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cop = wave % NCO, cip = (wave / NCO) % NCI, ksl = wave / (NCO * NCI);
+    const int co_tile = blockIdx.y, ci_tile = blockIdx.z;
+    const int co_base = co_tile * (32 * NCO), ci_base = ci_tile * (32 * NCI);
+    const int Hp = H + 2, Wp = W + 2;
+    const int CW = 1 << log2cw, CH = WG_PX >> log2cw, SW = CW + 2;
+    const int ncx = (W + CW - 1) >> log2cw, ncy = (H + CH - 1) / CH;
+    const int cpi = ncx * ncy;                       // chunks per image
+
+    // this wave's DMA pieces: lane byte offsets relative to the chunk origin, LDS destinations, dout (cy,cx) for masking
+    int p_off[PPW], p_lds[PPW], p_cyx[PPW];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int pid = wave + 4 * i;
+        const int row16 = lane >> 2, piece16 = (lane & 3) * 8;
+        if (pid < NPD) {
+            const int panel = pid / (WG_PX / 16), j = pid % (WG_PX / 16);
+            const int row = 16 * j + row16;
+            const int cy = row >> log2cw, cx = row & (CW - 1);
+            p_off[i] = ((cy * Wp + cx) * ldc_do + coff_do + co_base + panel * 32 + piece16) * 2;
+            p_lds[i] = panel * (WG_PX * PANEL_ROW) + j * 1024;
+            p_cyx[i] = cy | (cx << 8);
+        } else {
+            const int ps = pid - NPD;
+            const int panel = ps / NPSP, j = ps % NPSP;
+            const int row = 16 * j + row16;
+            const int iy = row / SW, ix = row - iy * SW;
+            p_off[i] = ((iy * Wp + ix) * ldc_in + coff_in + ci_base + panel * 32 + piece16) * 2;
+            p_lds[i] = DB + panel * (WG_SROWS * PANEL_ROW) + j * 1024;
+            p_cyx[i] = 0;
+        }
+    }
+
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+    const int c_begin = blockIdx.x * chunks_per_block;
+    const int c_end = min(nchunks, c_begin + chunks_per_block);
+    if (c_begin < c_end) wg_issue<NCO, NCI, PPW>(smem, src, dout, c_begin, 0, wave, H, W, ldc_in, ldc_do, log2cw, cpi, ncx, p_off, p_lds, p_cyx);
+    for (int c = c_begin; c < c_end; ++c) {
+        __syncthreads();
+        const int cur = (c - c_begin) & 1;
+        if (c + 1 < c_end) wg_issue<NCO, NCI, PPW>(smem, src, dout, c + 1, cur ^ 1, wave, H, W, ldc_in, ldc_do, log2cw, cpi, ncx, p_off, p_lds, p_cyx);
+        const unsigned char* pa = smem + cur * STAGE + cop * (WG_PX * PANEL_ROW);
+        const unsigned char* pb = smem + cur * STAGE + DB + cip * (WG_SROWS * PANEL_ROW);
+#pragma unroll
+        for (int kk = 0; kk < (WG_PX / 16) / KS; ++kk) {
+            const int ks = ksl + kk * KS;
+            const int row0 = 16 * ks;
+            const int cy = row0 >> log2cw, cx0 = row0 & (CW - 1);
+            const bf16x8 a = tr_frag(pa, row0, lane);
+#pragma unroll
+            for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+                for (int tx = 0; tx < 3; ++tx) {
+                    const bf16x8 b = tr_frag(pb, (cy + ty) * SW + cx0 + tx, lane);
+                    acc[ty * 3 + tx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[ty * 3 + tx], 0, 0, 0);
+                }
+        }
+    }
+    // D[row = co][col = ci]: partial[t][co][ci], lanes run along ci (two 128-B segments per store instruction)
+    const int r = lane & 31, h = lane >> 5;
+    const size_t pair = (size_t)(co_tile * NCO + cop) * (n_ci_tiles * NCI) + (ci_tile * NCI + cip);
+    float* part = slab + (pair * nparts + (size_t)blockIdx.x * KS + ksl) * WG_PART;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int co = (i & 3) + 8 * (i >> 2) + 4 * h;
+            part[t * 1024 + co * 32 + r] = acc[t][i];
+        }
+}
+
+// dWk[t][co][ci] += sum over partials of the (co/32, ci/32) pair.  grid = (elements / 256, partial groups); one float atomic
+// per (element, group) -- a few MB per launch.
+__global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ slab, float* __restrict__ dWk, int Cout, int Cin, int Cin_w,
+                                                      int nparts, int parts_per_group, int n_ci_panels) {
+    const int e = blockIdx.x * kThreads + threadIdx.x;
+    if (e >= 9 * Cout * Cin) return;
+    const int ci = e % Cin, rest = e / Cin, co = rest % Cout, t = rest / Cout;
+    const size_t pair = (size_t)(co >> 5) * n_ci_panels + (ci >> 5);
+    const int s0 = blockIdx.y * parts_per_group, s1 = min(nparts, s0 + parts_per_group);
+    const float* p = slab + (pair * nparts + s0) * WG_PART + t * 1024 + (co & 31) * 32 + (ci & 31);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int s = s0;
+    for (; s + 4 <= s1; s += 4, p += 4 * WG_PART) {
+        a0 += p[0]; a1 += p[WG_PART]; a2 += p[2 * WG_PART]; a3 += p[3 * WG_PART];
+    }
+    for (; s < s1; ++s, p += WG_PART) a0 += *p;
+    atomicAdd(dWk + ((size_t)t * Cout + co) * Cin_w + ci, (a0 + a1) + (a2 + a3));
+}
+
 template <typename K>
 int set_lds_limit(K kernel, size_t bytes) {
     if (bytes <= 48 * 1024) return FNET_OK;
@@ -327,6 +486,54 @@ int fnet_wgrad_mfma(const FnetOp& op, hipStream_t st) {
     FNET_CHECK_ARG(Cin % 8 == 0 && Cout % 8 == 0 && op.i[3] % 8 == 0 && op.i[4] % 8 == 0 && op.i[6] % 8 == 0 && op.i[7] % 8 == 0);
     const int nco = Cout > 32 ? 2 : 1, nci = Cin > 32 ? 2 : 1;
     const int tiles = ((Cout + 32 * nco - 1) / (32 * nco)) * ((Cin + 32 * nci - 1) / (32 * nci));
+    if (op.p[3]) {
+        // slab path: i[10] = B, i[11] = H, i[12] = slab capacity in partials (36 KB each)
+        const int B = op.i[10], H = op.i[11], W = Wp - 2;
+        FNET_CHECK_ARG(B > 0 && H >= 1 && W >= 1 && (long long)B * (H + 2) * Wp == Npix);
+        FNET_CHECK_ARG(op.i[4] + Cin <= op.i[3] && op.i[7] + Cout <= op.i[6]);
+        FNET_CHECK_ARG((long long)(H + 2) * Wp * op.i[3] * 2 < (1ll << 31) && (long long)(H + 2) * Wp * op.i[6] * 2 < (1ll << 31));
+        FNET_CHECK_ARG((op.p[0] % 16) == 0 && (op.p[1] % 16) == 0 && (op.p[3] % 16) == 0);
+        const int log2cw = W > 16 ? 5 : 4;
+        const int CW = 1 << log2cw, CH = WG_PX / CW;
+        const int nch = B * ((W + CW - 1) / CW) * ((H + CH - 1) / CH);
+        const int ks = 4 / (nco * nci);
+        const int co_tiles = (Cout + 32 * nco - 1) / (32 * nco), ci_tiles = (Cin + 32 * nci - 1) / (32 * nci);
+        // two blocks per CU over the whole launch
+        int splits = (512 + tiles - 1) / tiles;
+        if (splits > nch) splits = nch;
+        int cpb = (nch + splits - 1) / splits;
+        splits = (nch + cpb - 1) / cpb;
+        const int nparts = splits * ks;
+        const long long need = (long long)co_tiles * nco * ci_tiles * nci * nparts;
+        FNET_CHECK_ARG(need <= op.i[12]);
+        const bf16_t* src = (const bf16_t*)op.p[0];
+        const bf16_t* dout = (const bf16_t*)op.p[1];
+        float* slab = (float*)op.p[3];
+        const dim3 grid(splits, co_tiles, ci_tiles);
+#define WGD_LAUNCH(A, B_)                                                                                                  \
+    {                                                                                                                     \
+        const size_t lds = 2 * ((size_t)A * WG_PX * PANEL_ROW + (size_t)B_ * WG_SROWS * PANEL_ROW);                        \
+        int rc = set_lds_limit(k_wgrad_dma<A, B_>, lds);                                                                   \
+        if (rc) return rc;                                                                                                \
+        hipLaunchKernelGGL((k_wgrad_dma<A, B_>), grid, dim3(kThreads), lds, st, src, dout, slab, B, H, W, op.i[3], op.i[4], \
+                           op.i[6], op.i[7], log2cw, cpb, nch, nparts, ci_tiles);                                          \
+    }
+        if (nco == 2 && nci == 2) WGD_LAUNCH(2, 2)
+        else if (nco == 2 && nci == 1) WGD_LAUNCH(2, 1)
+        else if (nco == 1 && nci == 2) WGD_LAUNCH(1, 2)
+        else WGD_LAUNCH(1, 1)
+#undef WGD_LAUNCH
+        const int elems = 9 * Cout * Cin;
+        const int eb = (elems + kThreads - 1) / kThreads;
+        int groups = (1024 + eb - 1) / eb;
+        if (groups > nparts) groups = nparts;
+        const int ppg = (nparts + groups - 1) / groups;
+        groups = (nparts + ppg - 1) / ppg;
+        hipLaunchKernelGGL(k_wgrad_reduce, dim3(eb, groups), dim3(kThreads), 0, st, (const float*)slab, (float*)op.p[2], Cout, Cin, Cin_w,
+                           nparts, ppg, ci_tiles * nci);
+        FNET_LAUNCH_CHECK();
+        return FNET_OK;
+    }
     const int nchunks = (Npix + KP - 1) / KP;
     // aim for ~4 blocks per CU over the whole launch, at least 2 chunks per block to amortise the atomics
     int splits = (1024 + tiles - 1) / tiles;

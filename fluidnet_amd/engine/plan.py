@@ -163,6 +163,23 @@ def unet_param_shapes(cfg) -> "OrderedDict[str, Tuple[int, ...]]":
     return out
 
 
+WG_PART = 9 * 32 * 32          # floats per wave partial of the weight-gradient kernel (fnet_conv_mfma.hip)
+
+
+def wgrad_slab_parts(cfg) -> int:
+    """Upper bound of (co panels x ci panels x pixel splits x k-split waves) over the layers of `cfg`, mirroring the launch
+    geometry of fnet_wgrad_mfma: ~512 blocks per launch, 4 waves each."""
+    worst = 0
+    for k, s in unet_param_shapes(cfg).items():
+        if len(s) == 4 and s[2] == 3:
+            co, ci = s[0], max(16, s[1])
+            nco, nci = (2 if co > 32 else 1), (2 if ci > 32 else 1)
+            cot, cit = -(-co // (32 * nco)), -(-ci // (32 * nci))
+            splits = -(-512 // (cot * cit))
+            worst = max(worst, cot * nco * cit * nci * splits * (4 // (nco * nci)))
+    return worst
+
+
 def check_supported(cfg, H: int, W: int) -> None:
     """The HIP engine covers the UNet_medium family; anything else fails loudly (no fallback)."""
     bad = []
@@ -220,6 +237,8 @@ class PlanBuilder:
         # per-block (sum, sumsq) partials of the one-pass InstanceNorm statistics: [B][chunks <= ceil(2048/B)][C][2]
         cmax = cfg.base_channels * 2 ** cfg.depth
         self.stats_scratch = self.new_buf("stats_scratch", (B * ((2048 + B - 1) // B) * cmax * 2,), "f32")
+        # per-wave partial results of the weight-gradient kernel (36 KB each); see wgrad_slab_parts()
+        self.wgrad_slab = self.new_buf("wgrad_slab", (wgrad_slab_parts(cfg) * WG_PART,), "f32")
         self.convs: "OrderedDict[str, dict]" = OrderedDict()
         for k, s in self.shapes.items():
             if len(s) == 4 and s[2] == 3:
@@ -312,8 +331,8 @@ class PlanBuilder:
         npix = self.B * (src.H + 2) * (src.W + 2)
         assert src.C == c["Cin_pad"] and dout.C == c["Cout"], (conv, src.C, dout.C)
         self.op(ops, "WGRAD", [npix, src.W + 2, src.C, src.ldc, src.coff, dout.C, dout.ldc, dout.coff,
-                               self.impl_for(src.C, dout.C), c["Cin_pad"]],
-                p=[src.ref, dout.ref, Ref(c["dWk"])], tag=conv)
+                               self.impl_for(src.C, dout.C), c["Cin_pad"], self.B, src.H, self.wgrad_slab.numel // WG_PART],
+                p=[src.ref, dout.ref, Ref(c["dWk"]), Ref(self.wgrad_slab)], tag=conv)
         ops[-1].flops = self.conv_flops(conv, src.H, src.W)
 
     def e_stats(self, ops, raw: PV, st: Buf):

@@ -45,8 +45,10 @@ def _mk(B, H, W, cin, cout, ldi, coi, ldo, coo, dtype, impl):
     ops = []
     pb.e_conv(ops, PV(src, cin, coi), wk, Ref(bias), PV(dst, cout, coo), cin, cout, tag="conv")
     npix = B * (H + 2) * (W + 2)
-    pb.op(ops, "WGRAD", [npix, W + 2, cin, ldi, coi, cout, ldo, coo, pb.impl_for(cin, cout), cin],
-          p=[Ref(src), Ref(dout), Ref(dwk)], tag="wgrad")
+    slab = pb.new_buf("slab", (2048 * 9 * 32 * 32,), "f32")
+    slab.tensor = torch.zeros(slab.shape)
+    pb.op(ops, "WGRAD", [npix, W + 2, cin, ldi, coi, cout, ldo, coo, pb.impl_for(cin, cout), cin, B, H, 2048],
+          p=[Ref(src), Ref(dout), Ref(dwk), Ref(slab) if impl == "mfma" else None], tag="wgrad")
     return pb, ops
 
 

@@ -10,11 +10,14 @@ typedef uint16_t bf16_t;  // raw bf16 bits
 // ---------------------------------------------------------------- bf16 <-> f32
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 __device__ __forceinline__ bf16_t f2bf(float f) {
-    // round-to-nearest-even; NaN stays NaN (quiet)
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
+    // hardware conversion (v_cvt_pk_bf16_f32): round-to-nearest-even, NaN stays NaN
+    return __builtin_bit_cast(bf16_t, (__bf16)f);
+}
+__device__ __forceinline__ uint32_t f2bf_pk(float lo, float hi) {
+    typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 
 // 8-channel vector load/store for P-tensors (C % 8 == 0, channel offsets % 8 == 0)
@@ -48,7 +51,7 @@ struct Vec8<bf16_t> {
     __device__ __forceinline__ void store(bf16_t* p) const {
         uint32_t w[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) w[k] = (uint32_t)f2bf(v[2 * k]) | ((uint32_t)f2bf(v[2 * k + 1]) << 16);
+        for (int k = 0; k < 4; ++k) w[k] = f2bf_pk(v[2 * k], v[2 * k + 1]);
         *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
     }
 };
@@ -103,6 +106,25 @@ __device__ __forceinline__ float gelu_phi(float u, float& E) {
     p = fmaf(p, t, 0.254829592f);
     const float q = 0.5f * p * t * E;  // = 0.5*erfc(z)
     return u < 0.f ? q : 1.f - q;
+}
+template <int ACT>
+__device__ __forceinline__ float act_fwd_t(float u) {
+    if (ACT == FNET_ACT_RELU) return u > 0.f ? u : 0.f;
+    if (ACT == FNET_ACT_LEAKY) return u > 0.f ? u : 0.1f * u;
+    if (ACT == FNET_ACT_GELU) { float E; return u * gelu_phi(u, E); }
+    if (ACT == FNET_ACT_SILU) return u * __builtin_amdgcn_rcpf(1.f + __expf(-u));
+    return u;
+}
+template <int ACT>
+__device__ __forceinline__ float act_bwd_t(float u) {
+    if (ACT == FNET_ACT_RELU) return u > 0.f ? 1.f : 0.f;
+    if (ACT == FNET_ACT_LEAKY) return u > 0.f ? 1.f : 0.1f;
+    if (ACT == FNET_ACT_GELU) { float E; const float phi = gelu_phi(u, E); return fmaf(u * 0.3989422804014327f, E, phi); }
+    if (ACT == FNET_ACT_SILU) {
+        const float s = __builtin_amdgcn_rcpf(1.f + __expf(-u));
+        return s * (1.f + u * (1.f - s));
+    }
+    return 1.f;
 }
 __device__ __forceinline__ float act_fwd(float u, int act) {
     switch (act) {
@@ -168,6 +190,16 @@ extern int g_fnet_last_hip_error;
             return FNET_E_HIP;                   \
         }                                        \
     } while (0)
+
+#define DISPATCH_ACT(act, ...)                                                  \
+    switch (act) {                                                              \
+        case FNET_ACT_RELU: { constexpr int ACT = FNET_ACT_RELU; __VA_ARGS__; } break;       \
+        case FNET_ACT_LEAKY: { constexpr int ACT = FNET_ACT_LEAKY; __VA_ARGS__; } break;     \
+        case FNET_ACT_GELU: { constexpr int ACT = FNET_ACT_GELU; __VA_ARGS__; } break;       \
+        case FNET_ACT_SILU: { constexpr int ACT = FNET_ACT_SILU; __VA_ARGS__; } break;       \
+        case FNET_ACT_IDENTITY: { constexpr int ACT = FNET_ACT_IDENTITY; __VA_ARGS__; } break; \
+        default: return FNET_E_BADARG;                                          \
+    }
 
 #define DISPATCH_T(dtype, ...)                                       \
     if ((dtype) == FNET_BF16) { using T = bf16_t; __VA_ARGS__; }      \

@@ -50,7 +50,8 @@ template <int TN>
 __global__ __launch_bounds__(256, 2) void k_conv3x3_dma(const bf16_t* __restrict__ src, const bf16_t* __restrict__ Wk,
                                                         const float* __restrict__ bias, bf16_t* __restrict__ dst, int Npix, int Wp,
                                                         int Cin, int ldc_in, int coff_in, int Cout, int ldc_out, int coff_out,
-                                                        int n_mtiles, int n_ntiles, int rinp) {
+                                                        int n_mtiles, int n_ntiles, int rinp, float* __restrict__ stats_part, int H,
+                                                        int W) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NT = TN / 32;
     constexpr int WB = 9 * TN * 32;                 // weight image bytes
@@ -173,15 +174,93 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_dma(const bf16_t* __restrict
     constexpr int CH = TN / 8;             // 16-B chunks per pixel
     constexpr int PPI = kThreads / CH;     // pixels per pass
     const int chunk = tid % CH, px0 = tid / CH;
-    if (n0 + chunk * 8 < Cout) {
+    if (!stats_part) {
+        if (n0 + chunk * 8 < Cout) {
+#pragma unroll
+            for (int k = 0; k < TM / PPI; ++k) {
+                const int px = px0 + k * PPI;
+                const long long f = f0 + px;
+                if (f < Npix) {
+                    const uint4 v = *reinterpret_cast<const uint4*>(smem + px * PO + chunk * 16);
+                    *reinterpret_cast<uint4*>(dst + (size_t)f * ldc_out + coff_out + n0 + chunk * 8) = v;
+                }
+            }
+        }
+        return;
+    }
+    // Fused InstanceNorm statistics (ml/models/unet.py:22-23): while the tile streams out, every thread (fixed 8-channel
+    // chunk) sums x and x^2 of the bf16 values it stores, over interior pixels only, separately for the (at most two)
+    // images the tile touches (host guarantees (H+2)(W+2) >= 256).  Block partials go to
+    // stats_part[tile][slot 0/1][Cout][2] with plain stores; IN_STATS (tile mode) adds them in tile order -> deterministic.
+    const int Hp = H + 2, HpWp = Hp * Wp;
+    const int n_first = (int)(f0 / HpWp);
+    float sa[2][8], qa[2][8];
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { sa[sl][k] = 0.f; qa[sl][k] = 0.f; }
+    {
+        const int fi = (int)f0 + px0;
+        int n = fi / HpWp;
+        const int rem = fi - n * HpWp;
+        int y = rem / Wp, x = rem - y * Wp;
+        const bool cvalid = n0 + chunk * 8 < Cout;
 #pragma unroll
         for (int k = 0; k < TM / PPI; ++k) {
             const int px = px0 + k * PPI;
             const long long f = f0 + px;
-            if (f < Npix) {
+            if (f < Npix && cvalid) {
                 const uint4 v = *reinterpret_cast<const uint4*>(smem + px * PO + chunk * 16);
                 *reinterpret_cast<uint4*>(dst + (size_t)f * ldc_out + coff_out + n0 + chunk * 8) = v;
+                if (y >= 1 && y <= H && x >= 1 && x <= W) {
+                    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+                    const bool second = n != n_first;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float lo = __uint_as_float(w[e] << 16), hi = __uint_as_float(w[e] & 0xffff0000u);
+                        if (second) {
+                            sa[1][2 * e] += lo; qa[1][2 * e] = fmaf(lo, lo, qa[1][2 * e]);
+                            sa[1][2 * e + 1] += hi; qa[1][2 * e + 1] = fmaf(hi, hi, qa[1][2 * e + 1]);
+                        } else {
+                            sa[0][2 * e] += lo; qa[0][2 * e] = fmaf(lo, lo, qa[0][2 * e]);
+                            sa[0][2 * e + 1] += hi; qa[0][2 * e + 1] = fmaf(hi, hi, qa[0][2 * e + 1]);
+                        }
+                    }
+                }
             }
+            x += PPI;
+            while (x >= Wp) { x -= Wp; ++y; }
+            if (y >= Hp) { y -= Hp; ++n; }
+        }
+    }
+    // block reduction per slot through LDS (behind the output tile): red[256][16] -> R partial sums -> one value
+    float* red = reinterpret_cast<float*>(smem + TM * PO);
+    constexpr int NV = CH * 16;            // (chunk, value) pairs
+    constexpr int R = kThreads / NV;       // threads per pair in the first level
+    float* red2 = red + kThreads * 16;
+    float* out = stats_part + ((size_t)mt * 2) * Cout * 2;
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { red[tid * 16 + k] = sa[sl][k]; red[tid * 16 + 8 + k] = qa[sl][k]; }
+        __syncthreads();
+        {
+            const int pair = tid % NV, part = tid / NV;
+            const int cg = pair >> 4, k = pair & 15;
+            float a = 0.f;
+#pragma unroll 4
+            for (int p = part * (PPI / R); p < (part + 1) * (PPI / R); ++p) a += red[(p * CH + cg) * 16 + k];
+            red2[part * NV + pair] = a;
+        }
+        __syncthreads();
+        if (tid < NV) {
+            float a = 0.f;
+#pragma unroll
+            for (int p = 0; p < R; ++p) a += red2[p * NV + tid];
+            const int cg = tid >> 4, k = tid & 15;
+            const int c = n0 + cg * 8 + (k & 7);
+            if (c < Cout) out[((size_t)sl * Cout + c) * 2 + (k >> 3)] = a;
         }
     }
 }
@@ -455,8 +534,18 @@ int fnet_conv3x3_mfma(const FnetOp& op, hipStream_t st) {
     FNET_CHECK_ARG(op.p[0] && op.p[1] && op.p[3] && (op.p[0] % 16) == 0 && (op.p[1] % 16) == 0 && (op.p[3] % 16) == 0);
     const int TN = Cout > 32 ? 64 : 32;
     const int rinp = (TM + 2 * Wp + 2 + 31) / 32 * 32;
-    const size_t lds = 2 * ((size_t)rinp * 32 + (size_t)9 * TN * 32);
-    FNET_CHECK_ARG(lds <= 160 * 1024 && lds >= (size_t)TM * (TN * 2 + 16));
+    const size_t lds0 = 2 * ((size_t)rinp * 32 + (size_t)9 * TN * 32);
+    // optional fused InstanceNorm partial sums: p[4] = scratch (i[9] floats), i[10] = H (W = Wp - 2)
+    float* stats_part = (float*)op.p[4];
+    const int H = op.i[10], W = Wp - 2;
+    size_t lds_need = (size_t)TM * (TN * 2 + 16);
+    if (stats_part) {
+        FNET_CHECK_ARG(H >= 1 && W >= 1 && (H + 2) * Wp >= TM && Npix % ((H + 2) * Wp) == 0);
+        FNET_CHECK_ARG((long long)((Npix + TM - 1) / TM) * 4 * Cout <= (long long)op.i[9]);
+        lds_need += (size_t)kThreads * 16 * 4 + (size_t)kThreads * 4;
+    }
+    const size_t lds = lds0 > lds_need ? lds0 : lds_need;
+    FNET_CHECK_ARG(lds <= 160 * 1024);
     // the DMA window offsets are 32-bit
     FNET_CHECK_ARG((long long)(rinp + 2) * op.i[3] * 2 < (1ll << 30));
     const int n_mtiles = (Npix + TM - 1) / TM, n_ntiles = (Cout + TN - 1) / TN;
@@ -469,12 +558,12 @@ int fnet_conv3x3_mfma(const FnetOp& op, hipStream_t st) {
         int rc = set_lds_limit(k_conv3x3_dma<64>, lds);
         if (rc) return rc;
         hipLaunchKernelGGL(k_conv3x3_dma<64>, grid, dim3(kThreads), lds, st, src, Wk, bias, dst, Npix, Wp, Cin, op.i[3], op.i[4], Cout,
-                           op.i[6], op.i[7], n_mtiles, n_ntiles, rinp);
+                           op.i[6], op.i[7], n_mtiles, n_ntiles, rinp, stats_part, H, W);
     } else {
         int rc = set_lds_limit(k_conv3x3_dma<32>, lds);
         if (rc) return rc;
         hipLaunchKernelGGL(k_conv3x3_dma<32>, grid, dim3(kThreads), lds, st, src, Wk, bias, dst, Npix, Wp, Cin, op.i[3], op.i[4], Cout,
-                           op.i[6], op.i[7], n_mtiles, n_ntiles, rinp);
+                           op.i[6], op.i[7], n_mtiles, n_ntiles, rinp, stats_part, H, W);
     }
     FNET_LAUNCH_CHECK();
     return FNET_OK;

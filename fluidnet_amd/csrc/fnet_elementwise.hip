@@ -151,6 +151,7 @@ __global__ __launch_bounds__(256) void k_in_finalize(const float2* part, float2*
     if (i >= B * C) return;
     const int n = i / C, c = i - n * C;
     float sx = 0.f, sq = 0.f;
+#pragma unroll 8
     for (int j = 0; j < chunks; ++j) {
         const float2 v = part[((size_t)n * chunks + j) * C + c];
         sx += v.x; sq += v.y;
@@ -160,9 +161,29 @@ __global__ __launch_bounds__(256) void k_in_finalize(const float2* part, float2*
     stats[i] = make_float2(mean, rsqrtf(var + eps));
 }
 
+// statistics whose partial sums were produced by the convolution epilogue (k_conv3x3_dma): part[tile][slot][C] float2,
+// tile = 256 flattened padded pixels, slot = image index relative to the tile's first image
+__global__ __launch_bounds__(256) void k_in_finalize_tiles(const float2* part, float2* stats, int B, int C, int HpWp, float inv_hw, float eps) {
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    if (i >= B * C) return;
+    const int n = i / C, c = i - n * C;
+    const long long p0 = (long long)n * HpWp, p1 = p0 + HpWp - 1;
+    const int t0 = (int)(p0 >> 8), t1 = (int)(p1 >> 8);
+    float sx = 0.f, sq = 0.f;
+#pragma unroll 8
+    for (int t = t0; t <= t1; ++t) {
+        const int first = (int)(((long long)t << 8) / HpWp);
+        const float2 v = part[((size_t)t * 2 + (n - first)) * C + c];
+        sx += v.x; sq += v.y;
+    }
+    const float mean = sx * inv_hw;
+    const float var = fmaxf(sq * inv_hw - mean * mean, 0.f);
+    stats[i] = make_float2(mean, rsqrtf(var + eps));
+}
+
 // ------------------------------------------------------------------ APPLY
 // dst[n,y,x,c] = act(gamma*(raw[src]-mean)*rstd+beta) * drop(n,c) + res[src], over the padded domain
-template <typename T>
+template <typename T, int ACT>
 __global__ __launch_bounds__(256) void k_apply(const T* raw, const float2* stats, const float* gamma, const float* beta, const T* res, T* dst,
                         int H, int W, int C, int ldc_raw, int coff_raw, int ldc_res, int coff_res, int ldc_dst,
                         int coff_dst, int act, int pm, uint32_t site, uint32_t seed, float drop_p, int p_per_block) {
@@ -197,7 +218,7 @@ __global__ __launch_bounds__(256) void k_apply(const T* raw, const float2* stats
             Vec8<T> r;
             r.load(rbase + sp * ldc_raw);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) o.v[k] = act_fwd(fmaf(r.v[k], ca[k], cb[k]), act) * dsc[k];
+            for (int k = 0; k < 8; ++k) o.v[k] = act_fwd_t<ACT>(fmaf(r.v[k], ca[k], cb[k])) * dsc[k];
             if (sbase) {
                 Vec8<T> q;
                 q.load(sbase + sp * ldc_res);
@@ -238,7 +259,7 @@ __device__ __forceinline__ void fold_read8(const T* g, int n, int y, int x, int 
 // ------------------------------------------------------------------ INACT_BWD_REDUCE (pass 1)
 // G = fold(g1) + fold(g2); dz = G*drop*act'(u); S1 = sum dz, S2 = sum dz*xhat per (n,c).  Writes G (interior) and adds the
 // block's partial sums into S (zeroed by the plan before this op).
-template <typename T>
+template <typename T, int ACT>
 __global__ __launch_bounds__(256) void k_inact_bwd_reduce(const T* g1, const T* g2, const T* raw, const float2* stats, const float* gamma,
                                    const float* beta, T* G, float* S, float* dgamma, float* dbeta, int H, int W, int C, int ldc_g1,
                                    int coff_g1, int ldc_g2, int coff_g2, int ldc_raw, int coff_raw, int ldc_G, int coff_G,
@@ -284,7 +305,7 @@ __global__ __launch_bounds__(256) void k_inact_bwd_reduce(const T* g1, const T* 
                 const float u = fmaf(xh, gam[k], bet[k]);
                 float gq = go.v[k];
                 if (sizeof(T) == 2) gq = bf2f(f2bf(gq));
-                const float dz = gq * dsc[k] * act_bwd(u, act);
+                const float dz = gq * dsc[k] * act_bwd_t<ACT>(u);
                 s[k] += dz;
                 t[k] = fmaf(dz, xh, t[k]);
             }
@@ -309,7 +330,7 @@ __global__ __launch_bounds__(256) void k_inact_bwd_reduce(const T* g1, const T* 
 // ------------------------------------------------------------------ INACT_BWD_APPLY (pass 2)
 // d_raw = gamma*rstd*(dz - S1/HW - xhat*S2/HW) on the interior, 0 on the ring (so that d_raw can feed
 // the flattened dgrad / wgrad convolutions directly).
-template <typename T>
+template <typename T, int ACT>
 __global__ __launch_bounds__(256) void k_inact_bwd_apply(const T* G, const T* raw, const float2* stats, const float* gamma, const float* beta,
                                   const float2* S, T* draw, int H, int W, int C, int ldc_G, int coff_G, int ldc_raw,
                                   int coff_raw, int ldc_d, int coff_d, int act, uint32_t site, uint32_t seed, float drop_p,
@@ -350,7 +371,7 @@ __global__ __launch_bounds__(256) void k_inact_bwd_apply(const T* G, const T* ra
             for (int k = 0; k < 8; ++k) {
                 const float xh = fmaf(r.v[k], xa[k], xb[k]);
                 const float u = fmaf(xh, gam[k], bet[k]);
-                const float dz = g.v[k] * dsc[k] * act_bwd(u, act);
+                const float dz = g.v[k] * dsc[k] * act_bwd_t<ACT>(u);
                 o.v[k] = k0[k] * (dz - k1[k] - xh * k2[k]);
             }
         }
@@ -362,15 +383,24 @@ __global__ __launch_bounds__(256) void k_inact_bwd_apply(const T* G, const T* ra
 
 // ------------------------------------------------------------------ AFFINE_GRAD: dgamma += sum_n S2, dbeta += sum_n S1
 __global__ __launch_bounds__(256) void k_affine_grad(const float2* S, float* dgamma, float* dbeta, int B, int C) {
-    const int c = blockIdx.x * kThreads + threadIdx.x;
-    if (c >= C) return;
+    // block = 64 channels x 4 batch groups; the batch loop is split 4 ways and unrolled so the loads overlap
+    __shared__ float2 red[kThreads];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
     float a = 0.f, b = 0.f;
-    for (int n = 0; n < B; ++n) {
-        const float2 s = S[(size_t)n * C + c];
-        a += s.x; b += s.y;
+    if (c < C) {
+#pragma unroll 8
+        for (int n = g; n < B; n += 4) {
+            const float2 s = S[(size_t)n * C + c];
+            a += s.x; b += s.y;
+        }
     }
-    dbeta[c] += a;
-    dgamma[c] += b;
+    red[threadIdx.x] = make_float2(a, b);
+    __syncthreads();
+    if (g == 0 && c < C) {
+        const float2 r1 = red[threadIdx.x + 64], r2 = red[threadIdx.x + 128], r3 = red[threadIdx.x + 192];
+        dbeta[c] += (a + r1.x) + (r2.x + r3.x);
+        dgamma[c] += (b + r1.y) + (r2.y + r3.y);
+    }
 }
 
 // ------------------------------------------------------------------ FOLD_SUM: dst = fold(g1)+fold(g2) interior, 0 ring
@@ -632,10 +662,19 @@ int fnet_op_pack_input(const FnetOp& op, hipStream_t st) {
     return FNET_OK;
 }
 
-// IN_STATS  i: 0 B,1 H,2 W,3 C,4 ldc,5 coff,6 scratch floats; f: 0 eps; p: 0 raw, 1 stats float2[B][C] = (mean, rstd), 2 scratch|0
+// IN_STATS  i: 0 B,1 H,2 W,3 C,4 ldc,5 coff,6 scratch floats,7 mode (1 = scratch holds the conv epilogue's tile partials); f: 0 eps; p: 0 raw, 1 stats float2[B][C] = (mean, rstd), 2 scratch|0
 int fnet_op_in_stats(const FnetOp& op, hipStream_t st) {
     const int B = op.i[0], H = op.i[1], W = op.i[2], C = op.i[3];
     FNET_CHECK_ARG(B > 0 && H > 0 && W > 0 && vec_ok((void*)op.p[0], op.i[4], op.i[5], C, op.dtype) && op.p[1]);
+    if (op.i[7] == 1) {
+        // the producing convolution already wrote per-tile partial sums into the scratch (fnet_conv3x3_mfma)
+        FNET_CHECK_ARG(op.p[2] && (H + 2) * (W + 2) >= 256);
+        FNET_CHECK_ARG(((long long)B * (H + 2) * (W + 2) + 255) / 256 * 4 * C <= (long long)op.i[6]);
+        hipLaunchKernelGGL(k_in_finalize_tiles, dim3((B * C + kThreads - 1) / kThreads), dim3(kThreads), 0, st, (const float2*)op.p[2],
+                           (float2*)op.p[1], B, C, (H + 2) * (W + 2), 1.f / (float)(H * W), op.f[0]);
+        FNET_LAUNCH_CHECK();
+        return FNET_OK;
+    }
     if (op.dtype == FNET_BF16 && cg_ok(C, B) && op.p[2]) {
         // one coalesced pass into per-block partials + ordered finalize (bf16 plans; p[2] = scratch of i[6] floats);
         // fp32 plans, or no scratch, keep the exact two-pass kernel below
@@ -668,11 +707,11 @@ int fnet_op_apply(const FnetOp& op, hipStream_t st) {
     FNET_CHECK_ARG(op.f[0] >= 0.f && op.f[0] < 1.f && cg_ok(C, B));
     int chunks;
     const int per = cg_pixels_per_block((H + 2) * (W + 2), B, C, &chunks);
-    DISPATCH_T(op.dtype, hipLaunchKernelGGL(k_apply<T>, dim3(chunks, B), dim3(kThreads), 0, st,
+    DISPATCH_ACT(op.i[10], DISPATCH_T(op.dtype, hipLaunchKernelGGL((k_apply<T, ACT>), dim3(chunks, B), dim3(kThreads), 0, st,
                                             (const T*)op.p[0], (const float2*)op.p[1], (const float*)op.p[2],
                                             (const float*)op.p[3], (const T*)op.p[4], (T*)op.p[5], H, W, C, op.i[4],
                                             op.i[5], op.i[6], op.i[7], op.i[8], op.i[9], op.i[10], op.i[11],
-                                            (uint32_t)op.i[12], (uint32_t)op.i[13], op.f[0], per));
+                                            (uint32_t)op.i[12], (uint32_t)op.i[13], op.f[0], per)));
     FNET_LAUNCH_CHECK();
     return FNET_OK;
 }
@@ -691,12 +730,12 @@ int fnet_op_inact_bwd_reduce(const FnetOp& op, hipStream_t st) {
     FNET_CHECK_ARG(op.p[3] && op.p[4] && op.p[5] && op.p[7] && cg_ok(C, B) && ((op.p[8] == 0) == (op.p[9] == 0)));
     int chunks;
     const int per = cg_pixels_per_block(H * W, B, C, &chunks);
-    DISPATCH_T(op.dtype,
-               hipLaunchKernelGGL(k_inact_bwd_reduce<T>, dim3(chunks, B), dim3(kThreads), 0, st, (const T*)op.p[0],
+    DISPATCH_ACT(op.i[14], DISPATCH_T(op.dtype,
+               hipLaunchKernelGGL((k_inact_bwd_reduce<T, ACT>), dim3(chunks, B), dim3(kThreads), 0, st, (const T*)op.p[0],
                                   (const T*)op.p[1], (const T*)op.p[2], (const float2*)op.p[3], (const float*)op.p[4],
                                   (const float*)op.p[5], (T*)op.p[6], (float*)op.p[7], (float*)op.p[8], (float*)op.p[9], H, W, C, op.i[4], op.i[5],
                                   op.i[6], op.i[7], op.i[8], op.i[9], op.i[10], op.i[11], op.i[12], op.i[13], op.i[14],
-                                  op.i[15], (uint32_t)op.i[16], (uint32_t)op.i[17], op.f[0], per));
+                                  op.i[15], (uint32_t)op.i[16], (uint32_t)op.i[17], op.f[0], per)));
     FNET_LAUNCH_CHECK();
     return FNET_OK;
 }
@@ -712,11 +751,11 @@ int fnet_op_inact_bwd_apply(const FnetOp& op, hipStream_t st) {
     FNET_CHECK_ARG(op.p[2] && op.p[3] && op.p[4] && op.p[5] && cg_ok(C, B));
     int chunks;
     const int per = cg_pixels_per_block((H + 2) * (W + 2), B, C, &chunks);
-    DISPATCH_T(op.dtype, hipLaunchKernelGGL(k_inact_bwd_apply<T>, dim3(chunks, B), dim3(kThreads), 0,
+    DISPATCH_ACT(op.i[10], DISPATCH_T(op.dtype, hipLaunchKernelGGL((k_inact_bwd_apply<T, ACT>), dim3(chunks, B), dim3(kThreads), 0,
                                             st, (const T*)op.p[0], (const T*)op.p[1], (const float2*)op.p[2],
                                             (const float*)op.p[3], (const float*)op.p[4], (const float2*)op.p[5],
                                             (T*)op.p[6], H, W, C, op.i[4], op.i[5], op.i[6], op.i[7], op.i[8], op.i[9],
-                                            op.i[10], (uint32_t)op.i[11], (uint32_t)op.i[12], op.f[0], per));
+                                            op.i[10], (uint32_t)op.i[11], (uint32_t)op.i[12], op.f[0], per)));
     FNET_LAUNCH_CHECK();
     return FNET_OK;
 }
@@ -725,7 +764,7 @@ int fnet_op_inact_bwd_apply(const FnetOp& op, hipStream_t st) {
 int fnet_op_affine_grad(const FnetOp& op, hipStream_t st) {
     const int B = op.i[0], C = op.i[1];
     FNET_CHECK_ARG(B > 0 && C > 0 && op.p[0] && op.p[1] && op.p[2]);
-    hipLaunchKernelGGL(k_affine_grad, dim3((C + kThreads - 1) / kThreads), dim3(kThreads), 0, st, (const float2*)op.p[0],
+    hipLaunchKernelGGL(k_affine_grad, dim3((C + 63) / 64), dim3(kThreads), 0, st, (const float2*)op.p[0],
                        (float*)op.p[1], (float*)op.p[2], B, C);
     FNET_LAUNCH_CHECK();
     return FNET_OK;

@@ -236,7 +236,9 @@ class PlanBuilder:
         self.grads = self.new_buf("grads_flat", (off,), "f32", external=True)
         # per-block (sum, sumsq) partials of the one-pass InstanceNorm statistics: [B][chunks <= ceil(2048/B)][C][2]
         cmax = cfg.base_channels * 2 ** cfg.depth
-        self.stats_scratch = self.new_buf("stats_scratch", (B * ((2048 + B - 1) // B) * cmax * 2,), "f32")
+        # ... or, when the convolution epilogue produces them, [256-pixel tiles][2 image slots][C][2]
+        n_sc = max(B * ((2048 + B - 1) // B) * cmax * 2, ((B * (H + 2) * (W + 2) + 255) // 256) * 4 * cmax)
+        self.stats_scratch = self.new_buf("stats_scratch", (n_sc,), "f32")
         # per-wave partial results of the weight-gradient kernel (36 KB each); see wgrad_slab_parts()
         self.wgrad_slab = self.new_buf("wgrad_slab", (wgrad_slab_parts(cfg) * WG_PART,), "f32")
         self.convs: "OrderedDict[str, dict]" = OrderedDict()
@@ -319,11 +321,18 @@ class PlanBuilder:
         fl = 2.0 * self.B * H * W * 9 * c["Cin"] * c["Cout"]
         return fl / 4 if name.split("/")[0].endswith(".down") else fl
 
-    def e_conv(self, ops, src: PV, wbuf: Buf, bias: Optional[Ref], dst: PV, cin: int, cout: int, tag=""):
+    def fused_stats_ok(self, H: int, W: int, cin: int, cout: int) -> bool:
+        """The MFMA convolution can emit InstanceNorm partial sums from its epilogue when a 256-pixel tile touches at most
+        two images."""
+        return self.impl_for(cin, cout) == rt.CONV_MFMA and (H + 2) * (W + 2) >= 256
+
+    def e_conv(self, ops, src: PV, wbuf: Buf, bias: Optional[Ref], dst: PV, cin: int, cout: int, tag="", stats: bool = False):
         npix = self.B * (src.H + 2) * (src.W + 2)
         assert (dst.H, dst.W) == (src.H, src.W) and src.C == cin and dst.C == cout, (tag, src.C, cin, dst.C, cout)
-        self.op(ops, "CONV3X3", [npix, src.W + 2, cin, src.ldc, src.coff, cout, dst.ldc, dst.coff, self.impl_for(cin, cout)],
-                p=[src.ref, Ref(wbuf), bias, dst.ref], tag=tag)
+        sc = self.stats_scratch
+        self.op(ops, "CONV3X3", [npix, src.W + 2, cin, src.ldc, src.coff, cout, dst.ldc, dst.coff, self.impl_for(cin, cout),
+                                 sc.numel if stats else 0, src.H],
+                p=[src.ref, Ref(wbuf), bias, dst.ref, Ref(sc) if stats else None], tag=tag)
         ops[-1].flops = self.conv_flops(tag, src.H, src.W)
 
     def e_wgrad(self, ops, src: PV, dout: PV, conv: str):
@@ -335,9 +344,10 @@ class PlanBuilder:
                 p=[src.ref, dout.ref, Ref(c["dWk"]), Ref(self.wgrad_slab)], tag=conv)
         ops[-1].flops = self.conv_flops(conv, src.H, src.W)
 
-    def e_stats(self, ops, raw: PV, st: Buf):
+    def e_stats(self, ops, raw: PV, st: Buf, from_conv: bool = False):
         sc = self.stats_scratch
-        self.op(ops, "IN_STATS", [self.B, raw.H, raw.W, raw.C, raw.ldc, raw.coff, sc.numel], f=[1e-5], p=[raw.ref, Ref(st), Ref(sc)])
+        self.op(ops, "IN_STATS", [self.B, raw.H, raw.W, raw.C, raw.ldc, raw.coff, sc.numel, 1 if from_conv else 0], f=[1e-5],
+                p=[raw.ref, Ref(st), Ref(sc)])
 
     def e_apply(self, ops, u: Unit):
         raw = PV(u.raw, u.out.C)
@@ -358,8 +368,9 @@ class PlanBuilder:
         if out is None:
             out = PV(self.pbuf(f"{tape_name}/{conv}/act", H, W, cout), cout)
         u = Unit(conv, norm, xin, raw, st, out, res, drop_site, drop_p)
-        self.e_conv(ops, xin, c["Wf"], None, PV(raw, cout), c["Cin_pad"], cout, tag=conv)
-        self.e_stats(ops, PV(raw, cout), st)
+        fused = self.fused_stats_ok(H, W, c["Cin_pad"], cout)
+        self.e_conv(ops, xin, c["Wf"], None, PV(raw, cout), c["Cin_pad"], cout, tag=conv, stats=fused)
+        self.e_stats(ops, PV(raw, cout), st, from_conv=fused)
         self.e_apply(ops, u)
         return u
 

@@ -32,80 +32,109 @@ constexpr int PS = 48;      // (weight-gradient kernel) LDS pitch of a 16-channe
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void gbl_void_t;
 
-// ---- convolution, LDS-DMA double-buffered --------------------------------------------------------------------
-// LDS (one dynamic array): [weights buf0][weights buf1][input buf0][input buf1]; after the K loop the same memory holds
-// the bf16 output tile [256 px][TN co] for the coalesced store pass.
+// ---- convolution: persistent blocks, LDS-DMA double-buffered --------------------------------------------------
+// LDS (one dynamic array) = two stage buffers of BUF bytes: [weights 9*TN rows x 32 B | input RINP pixels x 32 B].
 //   input image  : RINP pixels (TM + 2Wp + 2 rounded up to 32) x 16 channels = 32 B per pixel, two 16-B slots
-//   weight image : 9*TN rows (tap, cout) x 16 channels = 32 B per row
-// Both images are filled by LDS-DMA (buffer_load/global_load ... lds: no VGPR round trip, no ds_write): one wave
-// instruction moves 64 x 16 B = 32 rows, landing linearly in LDS; the bank swizzle therefore lives in the per-lane
-// SOURCE address: row p keeps its two 16-B halves swapped when bit 3 of p is set, slot(p,h) = 2p + (h ^ ((p>>3)&1)),
-// which makes every ds_read_b128 fragment read (16 lanes = 16 consecutive rows, same half) hit 16 distinct slots.
-// The input goes through a buffer descriptor windowed on the tile's pixel run, so pixels before the start / past the
-// end of the tensor read as zero (the flattened-convolution semantics of the P-tensor layout, see fluidnet_hip.h).
-// Pipeline: barrier -> issue DMA of stage s+1 -> 9 taps x (2 + NT) fragment reads + 2*NT MFMAs on stage s.
-// MFMA orientation: A = weights (rows = cout), B = pixels, so D[cout][pixel] leaves 4 consecutive couts of one pixel in
-// each accumulator quad = one 8-B LDS store into the pixel-major output tile.
+//   weight image : 9*TN rows (tap, cout) x 16 channels = 32 B per row, from the K-blocked global layout
+//                  [Cin/16][9][Cout][16] (PREP_WEIGHTS), so one stage of weights is a contiguous slab
+// Both images are filled by LDS-DMA (buffer_load ... lds: no VGPR round trip, no ds_write): one wave instruction moves
+// 64 x 16 B = 32 rows, landing linearly in LDS; the bank swizzle therefore lives in the per-lane SOURCE address: row p
+// keeps its two 16-B halves swapped when bit 3 of p is set, slot(p,h) = 2p + (h ^ ((p>>3)&1)), which makes every
+// ds_read_b128 fragment read (16 lanes = 16 consecutive rows, same half) hit 16 distinct slots.  (Buffer form for both:
+// a FLAT-encoded global_load_lds makes hipcc wait lgkmcnt(0) before every fragment use.)  The input goes through a buffer
+// descriptor windowed on the tile's pixel run, so pixels before the start / past the end of the tensor read as zero (the
+// flattened-convolution semantics of the P-tensor layout, see fluidnet_hip.h).
+// Persistent: the grid is 2 blocks per CU; a block walks tiles L = blockIdx.x, +gridDim.x, ... and its stage pipeline
+// runs ACROSS tiles (stage 0 of the next tile is in flight during the last stage and the epilogue of the current one):
+// per-block prologues, which otherwise arrive as chip-wide DMA bursts with every wave idle, disappear.
+// Per stage: barrier -> issue DMA of the next stage -> 9 taps x (2 + NT) fragment reads, software-pipelined one tap
+// ahead, + 2*NT MFMAs.  MFMA orientation: A = weights (rows = cout), B = pixels, so D[cout][pixel] leaves 4 consecutive
+// couts of one pixel in each accumulator quad = one 8-B LDS store into the pixel-major output tile (XOR-swizzled
+// 16-B chunks, pitch TN*2), which then streams out 16 B per lane.
+// FNET_CONV_ABLATE (diagnostic builds only, tools/conv_bench.py): 1 = no MFMA, 2 = no DMA after the first stage
+#ifndef FNET_CONV_ABLATE
+#define FNET_CONV_ABLATE 0
+#endif
+
+struct ConvTile {          // wave-uniform description of one (pixel tile, cout tile) work item
+    long long f0;
+    int n0;
+    int in_lane_off;       // per lane
+    __amdgpu_buffer_rsrc_t rs;
+};
+
 template <int TN>
 __global__ __launch_bounds__(256, 2) void k_conv3x3_dma(const bf16_t* __restrict__ src, const bf16_t* __restrict__ Wk,
                                                         const float* __restrict__ bias, bf16_t* __restrict__ dst, int Npix, int Wp,
                                                         int Cin, int ldc_in, int coff_in, int Cout, int ldc_out, int coff_out,
-                                                        int n_mtiles, int n_ntiles, int rinp, float* __restrict__ stats_part, int H,
-                                                        int W) {
+                                                        int n_mtiles, int n_ntiles, int rinp, int bufsz, float* __restrict__ stats_part,
+                                                        int H, int W) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NT = TN / 32;
     constexpr int WB = 9 * TN * 32;                 // weight image bytes
     constexpr int NPW = 9 * TN / 32;                // weight DMA pieces per stage
-    const int IB = rinp * 32;                       // input image bytes
     const int npi = rinp >> 5;                      // input DMA pieces per stage
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
+    const int nst = Cin / KC;
 
-    // XCD-aware tile order: blocks with equal blockIdx % 8 share an L2; give each XCD a contiguous range of pixel tiles
-    // and run the cout tiles of one pixel tile back to back on it.
+    // XCD-aware tile order: work items with equal L % 8 run on blocks that share an L2 (gridDim.x is a multiple of 8); give
+    // each XCD a contiguous range of pixel tiles and run the cout tiles of one pixel tile back to back on it.
     const int cpx = (n_mtiles + 7) >> 3;
-    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-    const int mt = xcd * cpx + j / n_ntiles;
-    const int nt = j - (j / n_ntiles) * n_ntiles;
-    if (mt >= n_mtiles) return;
-    const long long f0 = (long long)mt * TM;
-    const int n0 = nt * TN;
-
-    // input window descriptor
-    const long long gbase = f0 - Wp - 1;
-    const long long wpix = gbase > 0 ? gbase : 0;
-    long long wbytes = ((long long)Npix - wpix) * ldc_in * 2;
-    const long long wmax = (long long)(rinp + 1) * ldc_in * 2;
-    if (wbytes > wmax) wbytes = wmax;
-    const __amdgpu_buffer_rsrc_t rs =
-        __builtin_amdgcn_make_buffer_rsrc((void*)(src + (size_t)wpix * ldc_in), 0, (int)wbytes, 0x00020000);
+    const int n_items = 8 * cpx * n_ntiles;
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)Wk, 0, 9 * Cout * Cin * 2, 0x00020000);
     const int swz = (lane >> 4) & 1;                // bit 3 of the row a DMA lane fills (row = 32*piece + lane/2)
     const int dh = (lane & 1) ^ swz;                // channel half this lane fetches
-    const int in_lane_off = (int)(((long long)(lane >> 1) + (gbase - wpix)) * ldc_in + coff_in + dh * 8) * 2;
     const int in_piece_stride = 32 * ldc_in * 2;
-    // weight source: row = 32*piece + lane/2 -> (tap, col)
-    const int wrow = lane >> 1;
+    const int wrow = lane >> 1;                     // weight source: row = 32*piece + lane/2 -> (tap, col)
 
-    auto issue = [&](int s, int buf) {
-        const int c0 = s * KC;
-        unsigned char* wdst = smem + buf * WB;
-        unsigned char* idst = smem + 2 * WB + buf * IB;
+    auto tile_of = [&](int L, ConvTile& T) -> bool {
+        // returns false when L is past the end or maps to a padding slot of the XCD layout
+        if (L >= n_items) return false;
+        const int xcd = L & 7, j = L >> 3;
+        const int mt = xcd * cpx + j / n_ntiles;
+        if (mt >= n_mtiles) return false;
+        T.f0 = (long long)mt * TM;
+        T.n0 = (j - (j / n_ntiles) * n_ntiles) * TN;
+        const long long gbase = T.f0 - Wp - 1;
+        const long long wpix = gbase > 0 ? gbase : 0;
+        long long wbytes = ((long long)Npix - wpix) * ldc_in * 2;
+        const long long wmax = (long long)(rinp + 1) * ldc_in * 2;
+        if (wbytes > wmax) wbytes = wmax;
+        T.rs = __builtin_amdgcn_make_buffer_rsrc((void*)(src + (size_t)wpix * ldc_in), 0, (int)wbytes, 0x00020000);
+        T.in_lane_off = (int)(((long long)(lane >> 1) + (gbase - wpix)) * ldc_in + coff_in + dh * 8) * 2;
+        return true;
+    };
+    auto issue = [&](const ConvTile& T, int s, int buf) {
+        unsigned char* wdst = smem + buf * bufsz;
+        unsigned char* idst = wdst + WB;
         for (int q = wave; q < npi + NPW; q += 4) {
             if (q < npi) {
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(idst + q * 1024), 16, in_lane_off + q * in_piece_stride + c0 * 2,
-                                                         0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(T.rs, (lds_void_t*)(idst + q * 1024), 16,
+                                                         T.in_lane_off + q * in_piece_stride + s * (KC * 2), 0, 0, 0);
             } else {
                 const int qw = q - npi;
                 const int row = qw * 32 + wrow;
                 const int t = row / TN;
-                int co = n0 + (row - t * TN);
+                int co = T.n0 + (row - t * TN);
                 co = co < Cout ? co : Cout - 1;
-                const bf16_t* g = Wk + ((size_t)t * Cout + co) * Cin + c0 + dh * 8;
-                __builtin_amdgcn_global_load_lds((gbl_void_t*)g, (lds_void_t*)(wdst + qw * 1024), 16, 0, 0);
+                const int woff = (int)(((((size_t)s * 9 + t) * Cout + co) * 16 + dh * 8) * 2);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_void_t*)(wdst + qw * 1024), 16, woff, 0, 0, 0);
             }
         }
     };
+
+    // fragment read addresses (bytes, relative to a stage buffer): 9 taps x 2 pixel sub-tiles; weights: lane base + immediates
+    unsigned xaddr[9][2];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int ms = 0; ms < 2; ++ms) {
+            const int p = wave * 64 + ms * 32 + r + (t / 3) * Wp + (t % 3);
+            xaddr[t][ms] = WB + (unsigned)(2 * p + (h ^ ((p >> 3) & 1))) * 16;
+        }
+    const unsigned waddr = (unsigned)(2 * r + (h ^ ((r >> 3) & 1))) * 16;
 
     f32x16 acc[2][NT];
 #pragma unroll
@@ -115,153 +144,181 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_dma(const bf16_t* __restrict
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[ms][ns][i] = 0.f;
 
-    // fragment read addresses (bytes, buffer 0): 9 taps x 2 pixel sub-tiles; weights: one lane base + immediates
-    unsigned xaddr[9][2];
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
-#pragma unroll
-        for (int ms = 0; ms < 2; ++ms) {
-            const int p = wave * 64 + ms * 32 + r + (t / 3) * Wp + (t % 3);
-            xaddr[t][ms] = 2 * WB + (unsigned)(2 * p + (h ^ ((p >> 3) & 1))) * 16;
-        }
-    const unsigned waddr = (unsigned)(2 * r + (h ^ ((r >> 3) & 1))) * 16;
-
-    const int nst = Cin / KC;
-    issue(0, 0);
-    for (int s = 0; s < nst; ++s) {
-        __syncthreads();  // stage s has landed (vmcnt(0) + barrier); every wave is done with the other buffer
-        if (s + 1 < nst) issue(s + 1, (s + 1) & 1);
-        const unsigned ib = (s & 1) ? (unsigned)IB : 0u;
-        const unsigned wb = (s & 1) ? (unsigned)WB : 0u;
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            bf16x8 xb[2], wa[NT];
-#pragma unroll
-            for (int ms = 0; ms < 2; ++ms) xb[ms] = *reinterpret_cast<const bf16x8*>(smem + xaddr[t][ms] + ib);
-#pragma unroll
-            for (int ns = 0; ns < NT; ++ns) wa[ns] = *reinterpret_cast<const bf16x8*>(smem + waddr + wb + (t * TN + ns * 32) * 32);
-#pragma unroll
-            for (int ms = 0; ms < 2; ++ms)
-#pragma unroll
-                for (int ns = 0; ns < NT; ++ns)
-                    acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ns], xb[ms], acc[ms][ns], 0, 0, 0);
-        }
-    }
-    __syncthreads();  // all fragment reads done: reuse LDS for the output tile
-
-    // D[row = cout][col = pixel]: lane (r, h) holds pixel r, couts (i&3) + 8*(i>>2) + 4*h
-    constexpr int PO = TN * 2 + 16;  // output tile pitch (bytes)
-#pragma unroll
-    for (int ns = 0; ns < NT; ++ns)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int col = ns * 32 + 8 * q + 4 * h;
-            float bv[4] = {0.f, 0.f, 0.f, 0.f};
-            if (bias) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) bv[k] = (n0 + col + k < Cout) ? bias[n0 + col + k] : 0.f;
+    ConvTile cur, nxt;
+    bool have = tile_of(blockIdx.x, cur);
+    if (!have) return;
+    int L = blockIdx.x;
+    unsigned g = 0;                       // running stage counter: stage buffer = g & 1
+    issue(cur, 0, 0);
+    while (true) {
+        bool have_next = false;
+        for (int s = 0; s < nst; ++s, ++g) {
+            __syncthreads();  // this stage has landed (vmcnt(0) + barrier); every wave is done with the other buffer
+#if FNET_CONV_ABLATE != 2
+            if (s + 1 < nst) {
+                issue(cur, s + 1, (g + 1) & 1);
+            } else {
+                // last stage of this tile: start the next tile's first stage now (it lands during the epilogue)
+                L += gridDim.x;
+                have_next = tile_of(L, nxt);
+                if (have_next) issue(nxt, 0, (g + 1) & 1);
             }
+#else
+            if (s + 1 == nst) { L += gridDim.x; have_next = tile_of(L, nxt); }
+#endif
+            const unsigned bb = (g & 1) ? (unsigned)bufsz : 0u;
+            // fragment reads run one tap ahead of the MFMAs (two register sets, static indexing after unrolling)
+            bf16x8 xb[2][2], wa[2][NT];
 #pragma unroll
-            for (int ms = 0; ms < 2; ++ms) {
-                const int px = wave * 64 + ms * 32 + r;
-                uint2 v;
-                v.x = (uint32_t)f2bf(acc[ms][ns][4 * q + 0] + bv[0]) | ((uint32_t)f2bf(acc[ms][ns][4 * q + 1] + bv[1]) << 16);
-                v.y = (uint32_t)f2bf(acc[ms][ns][4 * q + 2] + bv[2]) | ((uint32_t)f2bf(acc[ms][ns][4 * q + 3] + bv[3]) << 16);
-                *reinterpret_cast<uint2*>(smem + px * PO + col * 2) = v;
+            for (int ms = 0; ms < 2; ++ms) xb[0][ms] = *reinterpret_cast<const bf16x8*>(smem + xaddr[0][ms] + bb);
+#pragma unroll
+            for (int ns = 0; ns < NT; ++ns) wa[0][ns] = *reinterpret_cast<const bf16x8*>(smem + waddr + bb + (ns * 32) * 32);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int c = t & 1, n = c ^ 1;
+                if (t + 1 < 9) {
+#pragma unroll
+                    for (int ms = 0; ms < 2; ++ms) xb[n][ms] = *reinterpret_cast<const bf16x8*>(smem + xaddr[t + 1][ms] + bb);
+#pragma unroll
+                    for (int ns = 0; ns < NT; ++ns)
+                        wa[n][ns] = *reinterpret_cast<const bf16x8*>(smem + waddr + bb + ((t + 1) * TN + ns * 32) * 32);
+                }
+                __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of this tap's MFMAs (hipcc otherwise re-serialises them)
+#pragma unroll
+                for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+                    for (int ns = 0; ns < NT; ++ns)
+#if FNET_CONV_ABLATE == 1
+                        { asm volatile("" ::"v"(wa[c][ns]), "v"(xb[c][ms])); }
+#else
+                        acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[c][ns], xb[c][ms], acc[ms][ns], 0, 0, 0);
+#endif
             }
         }
-    __syncthreads();
-    constexpr int CH = TN / 8;             // 16-B chunks per pixel
-    constexpr int PPI = kThreads / CH;     // pixels per pass
-    const int chunk = tid % CH, px0 = tid / CH;
-    if (!stats_part) {
-        if (n0 + chunk * 8 < Cout) {
+        __syncthreads();  // all fragment reads of the last stage done: its buffer now holds the output tile
+
+        // D[row = cout][col = pixel]: lane (r, h) holds pixel r, couts (i&3) + 8*(i>>2) + 4*h.  Output tile [256 px][TN] bf16,
+        // pitch TN*2, 16-B chunk index XOR-swizzled with the pixel index.
+        unsigned char* ot = smem + ((g - 1) & 1) * bufsz;
+        constexpr int PO = TN * 2;
+        constexpr int CH = TN / 8;             // 16-B chunks per pixel
+        const long long f0 = cur.f0;
+        const int n0 = cur.n0;
+#pragma unroll
+        for (int ns = 0; ns < NT; ++ns)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int col = ns * 32 + 8 * q + 4 * h;
+                float bv[4] = {0.f, 0.f, 0.f, 0.f};
+                if (bias) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) bv[k] = (n0 + col + k < Cout) ? bias[n0 + col + k] : 0.f;
+                }
+#pragma unroll
+                for (int ms = 0; ms < 2; ++ms) {
+                    const int px = wave * 64 + ms * 32 + r;
+                    uint2 v;
+                    v.x = f2bf_pk(acc[ms][ns][4 * q + 0] + bv[0], acc[ms][ns][4 * q + 1] + bv[1]);
+                    v.y = f2bf_pk(acc[ms][ns][4 * q + 2] + bv[2], acc[ms][ns][4 * q + 3] + bv[3]);
+                    *reinterpret_cast<uint2*>(ot + px * PO + ((((col >> 3) ^ px) & (CH - 1)) << 4) + (col & 4) * 2) = v;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) acc[ms][ns][4 * q + k] = 0.f;
+                }
+            }
+        __syncthreads();
+        constexpr int PPI = kThreads / CH;     // pixels per pass
+        const int chunk = tid % CH, px0 = tid / CH;
+        const bool cvalid = n0 + chunk * 8 < Cout;
+        if (!stats_part) {
+            if (cvalid) {
+#pragma unroll
+                for (int k = 0; k < TM / PPI; ++k) {
+                    const int px = px0 + k * PPI;
+                    const long long f = f0 + px;
+                    if (f < Npix) {
+                        const uint4 v = *reinterpret_cast<const uint4*>(ot + px * PO + (((chunk ^ px) & (CH - 1)) << 4));
+                        *reinterpret_cast<uint4*>(dst + (size_t)f * ldc_out + coff_out + n0 + chunk * 8) = v;
+                    }
+                }
+            }
+        } else {
+            // Fused InstanceNorm statistics (ml/models/unet.py:22-23): while the tile streams out, every thread (fixed
+            // 8-channel chunk) sums x and x^2 of the bf16 values it stores, over interior pixels only, separately for the (at
+            // most two) images the tile touches (host guarantees (H+2)(W+2) >= 256).  Lanes that own the same chunk are
+            // combined with wave shuffles, the four waves through 2 KB of LDS, and the block partial goes to
+            // stats_part[tile][slot 0/1][Cout][2] with plain stores; IN_STATS (tile mode) adds them in tile order.
+            const int Hp = H + 2, HpWp = Hp * Wp;
+            const int n_first = (int)(f0 / HpWp);
+            const long long f_last = (f0 + TM - 1 < Npix ? f0 + TM - 1 : (long long)Npix - 1);
+            const int nslots = ((int)(f_last / HpWp) != n_first) ? 2 : 1;
+            float sa[2][8], qa[2][8];
+#pragma unroll
+            for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { sa[sl][k] = 0.f; qa[sl][k] = 0.f; }
+            const int fi = (int)f0 + px0;
+            int n = fi / HpWp;
+            const int rem = fi - n * HpWp;
+            int y = rem / Wp, x = rem - y * Wp;
 #pragma unroll
             for (int k = 0; k < TM / PPI; ++k) {
                 const int px = px0 + k * PPI;
                 const long long f = f0 + px;
-                if (f < Npix) {
-                    const uint4 v = *reinterpret_cast<const uint4*>(smem + px * PO + chunk * 16);
+                if (f < Npix && cvalid) {
+                    const uint4 v = *reinterpret_cast<const uint4*>(ot + px * PO + (((chunk ^ px) & (CH - 1)) << 4));
                     *reinterpret_cast<uint4*>(dst + (size_t)f * ldc_out + coff_out + n0 + chunk * 8) = v;
-                }
-            }
-        }
-        return;
-    }
-    // Fused InstanceNorm statistics (ml/models/unet.py:22-23): while the tile streams out, every thread (fixed 8-channel
-    // chunk) sums x and x^2 of the bf16 values it stores, over interior pixels only, separately for the (at most two)
-    // images the tile touches (host guarantees (H+2)(W+2) >= 256).  Block partials go to
-    // stats_part[tile][slot 0/1][Cout][2] with plain stores; IN_STATS (tile mode) adds them in tile order -> deterministic.
-    const int Hp = H + 2, HpWp = Hp * Wp;
-    const int n_first = (int)(f0 / HpWp);
-    float sa[2][8], qa[2][8];
+                    if (y >= 1 && y <= H && x >= 1 && x <= W) {
+                        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+                        const bool second = n != n_first;
 #pragma unroll
-    for (int sl = 0; sl < 2; ++sl)
-#pragma unroll
-        for (int k = 0; k < 8; ++k) { sa[sl][k] = 0.f; qa[sl][k] = 0.f; }
-    {
-        const int fi = (int)f0 + px0;
-        int n = fi / HpWp;
-        const int rem = fi - n * HpWp;
-        int y = rem / Wp, x = rem - y * Wp;
-        const bool cvalid = n0 + chunk * 8 < Cout;
-#pragma unroll
-        for (int k = 0; k < TM / PPI; ++k) {
-            const int px = px0 + k * PPI;
-            const long long f = f0 + px;
-            if (f < Npix && cvalid) {
-                const uint4 v = *reinterpret_cast<const uint4*>(smem + px * PO + chunk * 16);
-                *reinterpret_cast<uint4*>(dst + (size_t)f * ldc_out + coff_out + n0 + chunk * 8) = v;
-                if (y >= 1 && y <= H && x >= 1 && x <= W) {
-                    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-                    const bool second = n != n_first;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float lo = __uint_as_float(w[e] << 16), hi = __uint_as_float(w[e] & 0xffff0000u);
-                        if (second) {
-                            sa[1][2 * e] += lo; qa[1][2 * e] = fmaf(lo, lo, qa[1][2 * e]);
-                            sa[1][2 * e + 1] += hi; qa[1][2 * e + 1] = fmaf(hi, hi, qa[1][2 * e + 1]);
-                        } else {
-                            sa[0][2 * e] += lo; qa[0][2 * e] = fmaf(lo, lo, qa[0][2 * e]);
-                            sa[0][2 * e + 1] += hi; qa[0][2 * e + 1] = fmaf(hi, hi, qa[0][2 * e + 1]);
+                        for (int e = 0; e < 4; ++e) {
+                            const float lo = __uint_as_float(w[e] << 16), hi = __uint_as_float(w[e] & 0xffff0000u);
+                            if (second) {
+                                sa[1][2 * e] += lo; qa[1][2 * e] = fmaf(lo, lo, qa[1][2 * e]);
+                                sa[1][2 * e + 1] += hi; qa[1][2 * e + 1] = fmaf(hi, hi, qa[1][2 * e + 1]);
+                            } else {
+                                sa[0][2 * e] += lo; qa[0][2 * e] = fmaf(lo, lo, qa[0][2 * e]);
+                                sa[0][2 * e + 1] += hi; qa[0][2 * e + 1] = fmaf(hi, hi, qa[0][2 * e + 1]);
+                            }
                         }
                     }
                 }
+                x += PPI;
+                while (x >= Wp) { x -= Wp; ++y; }
+                if (y >= Hp) { y -= Hp; ++n; }
             }
-            x += PPI;
-            while (x >= Wp) { x -= Wp; ++y; }
-            if (y >= Hp) { y -= Hp; ++n; }
-        }
-    }
-    // block reduction per slot through LDS (behind the output tile): red[256][16] -> R partial sums -> one value
-    float* red = reinterpret_cast<float*>(smem + TM * PO);
-    constexpr int NV = CH * 16;            // (chunk, value) pairs
-    constexpr int R = kThreads / NV;       // threads per pair in the first level
-    float* red2 = red + kThreads * 16;
-    float* out = stats_part + ((size_t)mt * 2) * Cout * 2;
+            // lanes l and l + CH, l + 2CH, ... own the same chunk: butterfly over those lane bits, then lanes 0..CH-1 hold
+            // the wave's sums
+            float* red = reinterpret_cast<float*>(ot + TM * PO);     // [4 waves][CH][16] floats
+            const int mtile = (int)(f0 / TM);
+            float* out = stats_part + ((size_t)mtile * 2) * Cout * 2;
+            for (int sl = 0; sl < 2; ++sl) {
+                float v16[16];
+                if (sl < nslots) {
 #pragma unroll
-    for (int sl = 0; sl < 2; ++sl) {
-        __syncthreads();
+                    for (int k = 0; k < 8; ++k) { v16[k] = sl ? sa[1][k] : sa[0][k]; v16[8 + k] = sl ? qa[1][k] : qa[0][k]; }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { red[tid * 16 + k] = sa[sl][k]; red[tid * 16 + 8 + k] = qa[sl][k]; }
-        __syncthreads();
-        {
-            const int pair = tid % NV, part = tid / NV;
-            const int cg = pair >> 4, k = pair & 15;
-            float a = 0.f;
-#pragma unroll 4
-            for (int p = part * (PPI / R); p < (part + 1) * (PPI / R); ++p) a += red[(p * CH + cg) * 16 + k];
-            red2[part * NV + pair] = a;
-        }
-        __syncthreads();
-        if (tid < NV) {
-            float a = 0.f;
+                    for (int off = CH; off < 64; off <<= 1)
 #pragma unroll
-            for (int p = 0; p < R; ++p) a += red2[p * NV + tid];
-            const int cg = tid >> 4, k = tid & 15;
-            const int c = n0 + cg * 8 + (k & 7);
-            if (c < Cout) out[((size_t)sl * Cout + c) * 2 + (k >> 3)] = a;
+                        for (int k = 0; k < 16; ++k) v16[k] += __shfl_xor(v16[k], off, 64);
+                    if (lane < CH) {
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) red[(wave * CH + lane) * 16 + k] = v16[k];
+                    }
+                }
+                __syncthreads();
+                if (tid < CH * 16) {
+                    float a = 0.f;
+                    if (sl < nslots) a = (red[tid] + red[CH * 16 + tid]) + (red[2 * CH * 16 + tid] + red[3 * CH * 16 + tid]);
+                    const int cg = tid >> 4, k = tid & 15;
+                    const int c = n0 + cg * 8 + (k & 7);
+                    if (c < Cout) out[((size_t)sl * Cout + c) * 2 + (k >> 3)] = a;
+                }
+                __syncthreads();
+            }
         }
+        if (!have_next) break;
+        cur = nxt;
     }
 }
 
@@ -534,22 +591,35 @@ int fnet_conv3x3_mfma(const FnetOp& op, hipStream_t st) {
     FNET_CHECK_ARG(op.p[0] && op.p[1] && op.p[3] && (op.p[0] % 16) == 0 && (op.p[1] % 16) == 0 && (op.p[3] % 16) == 0);
     const int TN = Cout > 32 ? 64 : 32;
     const int rinp = (TM + 2 * Wp + 2 + 31) / 32 * 32;
-    const size_t lds0 = 2 * ((size_t)rinp * 32 + (size_t)9 * TN * 32);
     // optional fused InstanceNorm partial sums: p[4] = scratch (i[9] floats), i[10] = H (W = Wp - 2)
     float* stats_part = (float*)op.p[4];
     const int H = op.i[10], W = Wp - 2;
-    size_t lds_need = (size_t)TM * (TN * 2 + 16);
     if (stats_part) {
         FNET_CHECK_ARG(H >= 1 && W >= 1 && (H + 2) * Wp >= TM && Npix % ((H + 2) * Wp) == 0);
         FNET_CHECK_ARG((long long)((Npix + TM - 1) / TM) * 4 * Cout <= (long long)op.i[9]);
-        lds_need += (size_t)kThreads * 16 * 4 + (size_t)kThreads * 4;
     }
-    const size_t lds = lds0 > lds_need ? lds0 : lds_need;
+    // one stage buffer: weights + input run, and big enough for the output tile (+ 2 KB of statistics scratch)
+    size_t bufsz = (size_t)rinp * 32 + (size_t)9 * TN * 32;
+    const size_t need = (size_t)TM * TN * 2 + 4 * (TN / 8) * 16 * 4;
+    if (bufsz < need) bufsz = need;
+    const size_t lds = 2 * bufsz;
     FNET_CHECK_ARG(lds <= 160 * 1024);
     // the DMA window offsets are 32-bit
     FNET_CHECK_ARG((long long)(rinp + 2) * op.i[3] * 2 < (1ll << 30));
     const int n_mtiles = (Npix + TM - 1) / TM, n_ntiles = (Cout + TN - 1) / TN;
-    const dim3 grid(8 * ((n_mtiles + 7) / 8) * n_ntiles);
+    const int n_items = 8 * ((n_mtiles + 7) / 8) * n_ntiles;
+    // persistent grid: two blocks per CU (LDS allows 2 at <= 80 KB each), a multiple of 8 for the XCD mapping
+    int cus = 256;
+    {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            cus = prop.multiProcessorCount;
+    }
+    int nblk = (lds <= 80 * 1024 ? 2 : 1) * cus;
+    nblk = (nblk + 7) / 8 * 8;
+    if (nblk > n_items) nblk = n_items;
+    const dim3 grid(nblk);
     const bf16_t* src = (const bf16_t*)op.p[0];
     const bf16_t* Wk = (const bf16_t*)op.p[1];
     const float* bias = (const float*)op.p[2];
@@ -558,12 +628,12 @@ int fnet_conv3x3_mfma(const FnetOp& op, hipStream_t st) {
         int rc = set_lds_limit(k_conv3x3_dma<64>, lds);
         if (rc) return rc;
         hipLaunchKernelGGL(k_conv3x3_dma<64>, grid, dim3(kThreads), lds, st, src, Wk, bias, dst, Npix, Wp, Cin, op.i[3], op.i[4], Cout,
-                           op.i[6], op.i[7], n_mtiles, n_ntiles, rinp, stats_part, H, W);
+                           op.i[6], op.i[7], n_mtiles, n_ntiles, rinp, (int)bufsz, stats_part, H, W);
     } else {
         int rc = set_lds_limit(k_conv3x3_dma<32>, lds);
         if (rc) return rc;
         hipLaunchKernelGGL(k_conv3x3_dma<32>, grid, dim3(kThreads), lds, st, src, Wk, bias, dst, Npix, Wp, Cin, op.i[3], op.i[4], Cout,
-                           op.i[6], op.i[7], n_mtiles, n_ntiles, rinp, stats_part, H, W);
+                           op.i[6], op.i[7], n_mtiles, n_ntiles, rinp, (int)bufsz, stats_part, H, W);
     }
     FNET_LAUNCH_CHECK();
     return FNET_OK;

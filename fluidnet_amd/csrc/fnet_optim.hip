@@ -9,17 +9,21 @@ constexpr int kThreads = 256;
 // Wf[t][co][ci] = W[co][ci][t]            (ci < Cin, else 0)        forward conv, K dim = Cin_pad
 // Wd[t][ci][co] = W[co][ci][8-t]          (ci < Cin, else 0)        dgrad as a conv: rows = Cout_d (padded Cin), K dim = Cout
 template <typename T>
-__global__ __launch_bounds__(256) void k_prep_weights(const float* W, T* Wf, T* Wd, int Cout, int Cin, int Cin_pad, int Cout_d) {
+__global__ __launch_bounds__(256) void k_prep_weights(const float* W, T* Wf, T* Wd, int Cout, int Cin, int Cin_pad, int Cout_d, int blocked) {
+    // logical layouts Wf[t][co][ci], Wd[t][ci][co] (flipped taps); "blocked" (MFMA convolution) stores the K axis in
+    // 16-channel blocks outermost, [K/16][t][row][16], so that one LDS-DMA stage of the conv is a contiguous slab
     const int idx = blockIdx.x * kThreads + threadIdx.x;
     const int nf = 9 * Cout * Cin_pad;
     const int nd = Wd ? 9 * Cout_d * Cout : 0;
     if (idx < nf) {
         const int ci = idx % Cin_pad, co = (idx / Cin_pad) % Cout, t = idx / (Cin_pad * Cout);
-        st1<T>(Wf + idx, ci < Cin ? W[((size_t)co * Cin + ci) * 9 + t] : 0.f);
+        const size_t o = (blocked & 1) ? ((((size_t)(ci >> 4) * 9 + t) * Cout + co) * 16 + (ci & 15)) : (size_t)idx;
+        st1<T>(Wf + o, ci < Cin ? W[((size_t)co * Cin + ci) * 9 + t] : 0.f);
     } else if (idx < nf + nd) {
         const int j = idx - nf;
         const int co = j % Cout, ci = (j / Cout) % Cout_d, t = j / (Cout * Cout_d);
-        st1<T>(Wd + j, ci < Cin ? W[((size_t)co * Cin + ci) * 9 + (8 - t)] : 0.f);
+        const size_t o = (blocked & 2) ? ((((size_t)(co >> 4) * 9 + t) * Cout_d + ci) * 16 + (co & 15)) : (size_t)j;
+        st1<T>(Wd + o, ci < Cin ? W[((size_t)co * Cin + ci) * 9 + (8 - t)] : 0.f);
     }
 }
 
@@ -71,9 +75,10 @@ __global__ __launch_bounds__(256) void k_adam(float* p, const float* g, float* m
 int fnet_op_prep_weights(const FnetOp& op, hipStream_t st) {
     const int Cout = op.i[0], Cin = op.i[1], Cin_pad = op.i[2], Cout_d = op.i[3];
     FNET_CHECK_ARG(Cout > 0 && Cin > 0 && Cin_pad >= Cin && op.p[0] && op.p[1] && (op.p[2] == 0 || Cout_d >= Cin));
+    FNET_CHECK_ARG(op.i[4] >= 0 && op.i[4] <= 3 && (!(op.i[4] & 1) || Cin_pad % 16 == 0) && (!(op.i[4] & 2) || Cout % 16 == 0));
     const int total = 9 * Cout * Cin_pad + (op.p[2] ? 9 * Cout_d * Cout : 0);
     DISPATCH_T(op.dtype, hipLaunchKernelGGL(k_prep_weights<T>, dim3((total + kThreads - 1) / kThreads), dim3(kThreads), 0, st,
-                                            (const float*)op.p[0], (T*)op.p[1], (T*)op.p[2], Cout, Cin, Cin_pad, Cout_d));
+                                            (const float*)op.p[0], (T*)op.p[1], (T*)op.p[2], Cout, Cin, Cin_pad, Cout_d, op.i[4]));
     FNET_LAUNCH_CHECK();
     return FNET_OK;
 }

@@ -10,6 +10,7 @@ rollout loss = ml/training/trainer.py:311-385; optimiser = trainer.py:190-195.
 from __future__ import annotations
 
 import math
+import os
 from collections import OrderedDict
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence, Tuple
@@ -324,6 +325,8 @@ class PlanBuilder:
     def fused_stats_ok(self, H: int, W: int, cin: int, cout: int) -> bool:
         """The MFMA convolution can emit InstanceNorm partial sums from its epilogue when a 256-pixel tile touches at most
         two images."""
+        if os.environ.get("FNET_FUSED_STATS", "0") != "1":      # measured: the epilogue costs as much as the separate one-pass kernel
+            return False
         return self.impl_for(cin, cout) == rt.CONV_MFMA and (H + 2) * (W + 2) >= 256
 
     def e_conv(self, ops, src: PV, wbuf: Buf, bias: Optional[Ref], dst: PV, cin: int, cout: int, tag="", stats: bool = False):
@@ -574,7 +577,9 @@ class PlanBuilder:
     # -------------------------------------------------------------------------------------------- weights / optimiser
     def emit_prep_weights(self, ops) -> None:
         for name, c in self.convs.items():
-            self.op(ops, "PREP_WEIGHTS", [c["Cout"], c["Cin"], c["Cin_pad"], c["Cout_d"]],
+            blocked = (1 if self.impl_for(c["Cin_pad"], c["Cout"]) == rt.CONV_MFMA else 0) | \
+                      (2 if self.impl_for(c["Cout"], c["Cout_d"]) == rt.CONV_MFMA else 0)
+            self.op(ops, "PREP_WEIGHTS", [c["Cout"], c["Cin"], c["Cin_pad"], c["Cout_d"], blocked],
                     p=[self.pref(name + ".weight"), Ref(c["Wf"]), Ref(c["Wd"])], tag=name)
 
     def emit_zero(self, ops, buf: Buf) -> None:

@@ -8,7 +8,8 @@ from typing import Optional
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libfluidnet_hip.so")
+# FNET_LIB overrides the library path (diagnostic / ablation builds made by tools/conv_bench.py); the default is the in-tree build
+LIB_PATH = os.environ.get("FNET_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libfluidnet_hip.so")
 
 # mirrors `struct FnetOp` (include/fluidnet_hip.h)
 OP_DTYPE = np.dtype([("op", "<i4"), ("dtype", "<i4"), ("i", "<i4", (30,)), ("f", "<f4", (8,)), ("p", "<u8", (10,))], align=True)

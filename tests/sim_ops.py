@@ -140,6 +140,8 @@ class Sim:
         src = self.rd(r.p[0], cin, ldc_in, coff_in)
         Wk = r.p[1].buf.tensor.float()                     # [9][cout][cin]
         assert tuple(Wk.shape) == (9, cout, cin), (r.tag, Wk.shape, cout, cin)
+        if impl == rt.CONV_MFMA:                           # the MFMA kernel reads the K-blocked layout [cin/16][9][cout][16]
+            Wk = Wk.reshape(cin // 16, 9, cout, 16).permute(1, 2, 0, 3).reshape(9, cout, cin)
         xs, n = self._flat_conv_inputs(src, Wp)
         assert n == npix
         out = torch.zeros(npix, cout)
@@ -308,13 +310,18 @@ class Sim:
 
     def op_PREP_WEIGHTS(self, r):
         cout, cin, cin_pad, cout_d = r.i[:4]
+        blocked = r.i[4] if len(r.i) > 4 else 0
         W = self.flat(r.p[0])[: cout * cin * 9].view(cout, cin, 9).float()
         Wf = torch.zeros(9, cout, cin_pad)
         Wf[:, :, :cin] = W.permute(2, 0, 1)
+        if blocked & 1:
+            Wf = Wf.reshape(9, cout, cin_pad // 16, 16).permute(2, 0, 1, 3).reshape(9, cout, cin_pad)
         r.p[1].buf.tensor.copy_(Wf.to(self.T))
         if r.p[2] is not None:
             Wd = torch.zeros(9, cout_d, cout)
             Wd[:, :cin, :] = W.flip(2).permute(2, 1, 0)
+            if blocked & 2:
+                Wd = Wd.reshape(9, cout_d, cout // 16, 16).permute(2, 0, 1, 3).reshape(9, cout_d, cout)
             r.p[2].buf.tensor.copy_(Wd.to(self.T))
 
     def op_UNPREP_WGRAD(self, r):

@@ -27,6 +27,7 @@ from fluidnet_amd.engine import runtime as rt  # noqa: E402
 from fluidnet_amd.engine.rollout_plan import RolloutInferPlan  # noqa: E402
 from fluidnet_amd.engine.train_plan import RolloutTrainPlan  # noqa: E402
 from fluidnet_amd.models.unet import UNet, UNetConfig  # noqa: E402
+from fluidnet_amd.training.dp import dp_train_step, torch_all_reduce  # noqa: E402
 from fluidnet_amd.training.physics_loss import PhysicsAwareLoss  # noqa: E402
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0      # MI355X dense bf16 (MI355X_MICROARCH.md)
@@ -87,15 +88,7 @@ class TrainStepper:
         p = self.plan
         p.set_adam_scalars(self.lr, self.t)
         p.set_dropout_seed(self.t * 7919 + 13)
-        if self.world == 1:
-            p.run(("fwd", "fin", "bwd", "opt"))
-            return
-        p.run(("fwd",))
-        p.gcnt.tensor.copy_(torch.stack([s.tensor[5] for s in p.sums]))
-        self.dist.all_reduce(p.gcnt.tensor)
-        p.run(("fin", "bwd"))
-        self.dist.all_reduce(p.pb.grads.tensor, op=self.dist.ReduceOp.AVG)
-        p.run(("opt",))
+        dp_train_step(p, self.world, torch_all_reduce(self.dist) if self.world > 1 else None)
 
 
 def profile_ops(plan_arrays, recs_by_section, dump_path=None):

@@ -15,6 +15,8 @@
 // [pixel][32-channel] panels (64-B rows: the four rows of a transposed block tile all 64 banks).  Each wave owns one
 // (co-panel, ci-panel) pair and keeps all nine taps' 32x32 accumulators in registers (144 VGPRs); the pixel axis is
 // split across blocks and reduced with fp32 atomics whose lanes run along ci (128-B segments).
+#include <stdlib.h>
+
 #include "fnet_common.h"
 
 namespace {
@@ -658,7 +660,8 @@ int fnet_wgrad_mfma(const FnetOp& op, hipStream_t st) {
         const int ks = 4 / (nco * nci);
         const int co_tiles = (Cout + 32 * nco - 1) / (32 * nco), ci_tiles = (Cin + 32 * nci - 1) / (32 * nci);
         // two blocks per CU over the whole launch
-        int splits = (512 + tiles - 1) / tiles;
+        static const int target_blocks = [] { const char* e = getenv("FNET_WG_BLOCKS"); return e ? atoi(e) : 512; }();
+        int splits = (target_blocks + tiles - 1) / tiles;
         if (splits > nch) splits = nch;
         int cpb = (nch + splits - 1) / splits;
         splits = (nch + cpb - 1) / cpb;

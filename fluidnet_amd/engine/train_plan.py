@@ -116,10 +116,13 @@ class RolloutTrainPlan:
             a = self._lowered["opt"][-1]
             a["f"][0], a["f"][4], a["f"][5] = lr, bc1, bc2s
 
-    def bind(self, device, params_flat, grads_flat) -> int:
-        """Allocate all internal buffers on `device` and lower the sections (device must be a GPU for run())."""
+    def bind(self, device, params_flat, grads_flat, adam_m=None, adam_v=None) -> int:
+        """Allocate all internal buffers on `device` and lower the sections (device must be a GPU for run()).  adam_m / adam_v:
+        externally owned Adam moment buffers (so that several plans of different batch shapes share one optimizer state)."""
         self.pb.params.tensor = params_flat
         self.pb.grads.tensor = grads_flat
+        if adam_m is not None:
+            self.m.tensor, self.v.tensor = adam_m, adam_v
         nbytes = allocate(self.pb, device)
         if str(device) != "cpu":
             self._lowered = {k: lower(self.pb, v) for k, v in self.sections.items()}

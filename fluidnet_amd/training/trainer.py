@@ -1,0 +1,279 @@
+"""Trainer with the reference's constructor and method surface (ml/training/trainer.py:34-42,142,210,311,606,717,765) over
+the MI355X engine.
+
+  Trainer(model, train_loader, val_loader, config: TrainingConfig, device)
+  .train()  .train_epoch() -> dict  .validate() -> dict  ._compute_rollout_loss(x_0, y_seq, masks) -> (loss, dict, pred)
+  .save_checkpoint(epoch, final=False)  .load_checkpoint(path) -> epoch
+
+Two execution engines for the optimisation step of train_epoch (trainer.py:142-208):
+  engine="plan" (default): the whole step -- K forwards, physics losses, BPTT backward, clip, Adam -- is ONE native plan
+      (fluidnet_amd.engine.train_plan.RolloutTrainPlan) replayed per batch with no host sync; batches whose shape has no
+      plan yet build one (at most `max_plans` shapes, e.g. the ragged last batch), others fall back to the autograd engine.
+  engine="autograd": the literal loop of the reference (_compute_rollout_loss + loss.backward()) through the
+      torch.autograd wrappers of fluidnet_amd.UNet / PhysicsAwareLoss, followed by FusedClipAdam.
+Both give the loss dict keys of the reference (mse, divergence, gradient, emitter, total).
+Not carried over: MLflow logging, matplotlib plots, GradScaler (bf16 needs none), the torchmetrics-based validation
+metrics -- validate() returns the averaged loss terms only.
+With torch.distributed initialised (one process per GPU) the plan engine runs the data-parallel step of
+fluidnet_amd/training/dp.py.
+"""
+from __future__ import annotations
+
+import time
+from pathlib import Path
+from typing import Any, Dict, Optional, Tuple
+
+import torch
+
+from ..engine.train_plan import RolloutTrainPlan
+from .dp import dp_train_step, torch_all_reduce
+from .early_stopping import EarlyStopping
+from .optim import FusedClipAdam
+from .physics_loss import PhysicsAwareLoss
+
+
+class _Scheduler:
+    """plateau / cosine / step learning-rate schedules with torch's semantics, acting on FusedClipAdam.param_groups."""
+
+    def __init__(self, opt: FusedClipAdam, cfg) -> None:
+        import math
+        self.opt, self.cfg, self.kind = opt, cfg, cfg.lr_scheduler_type
+        if self.kind not in ("plateau", "cosine", "step"):
+            raise ValueError(f"Unknown scheduler type: {self.kind}")
+        self.base_lr = opt.param_groups[0]["lr"]
+        self.epoch = 0
+        self.best, self.bad = float("inf"), 0
+        self._math = math
+
+    def step(self, metric: Optional[float] = None) -> None:
+        c, g = self.cfg, self.opt.param_groups[0]
+        self.epoch += 1
+        if self.kind == "plateau":          # ReduceLROnPlateau(mode="min", threshold=1e-4 rel)
+            if metric is not None and metric < self.best * (1 - 1e-4):
+                self.best, self.bad = metric, 0
+            else:
+                self.bad += 1
+            if self.bad > c.lr_scheduler_patience:
+                g["lr"] = max(g["lr"] * c.lr_scheduler_factor, c.lr_scheduler_min_lr)
+                self.bad = 0
+        elif self.kind == "cosine":         # CosineAnnealingLR(T_max, eta_min), closed form
+            g["lr"] = c.lr_scheduler_min_lr + (self.base_lr - c.lr_scheduler_min_lr) * \
+                (1 + self._math.cos(self._math.pi * self.epoch / c.lr_scheduler_t_max)) / 2
+        else:                               # StepLR(step_size, gamma)
+            g["lr"] = self.base_lr * c.lr_scheduler_factor ** (self.epoch // c.lr_scheduler_step_size)
+
+    def state_dict(self) -> dict:
+        return {"epoch": self.epoch, "best": self.best, "bad": self.bad, "base_lr": self.base_lr}
+
+    def load_state_dict(self, s: dict) -> None:
+        self.epoch, self.best, self.bad, self.base_lr = s["epoch"], s["best"], s["bad"], s["base_lr"]
+
+
+class Trainer:
+    def __init__(self, model, train_loader, val_loader, config, device: str, *, engine: str = "plan", max_plans: int = 2) -> None:
+        if engine not in ("plan", "autograd"):
+            raise ValueError("engine must be 'plan' or 'autograd'")
+        self.model, self.train_loader, self.val_loader = model, train_loader, val_loader
+        self.config = config.model_copy()
+        self.device = device
+        self.engine, self.max_plans = engine, max_plans
+        self.gradient_clip_norm = config.gradient_clip_norm
+        self.gradient_clip_enabled = config.gradient_clip_enabled
+        pl = config.physics_loss
+        self.criterion = PhysicsAwareLoss(
+            mse_weight=pl.mse_weight, divergence_weight=pl.divergence_weight, gradient_weight=pl.gradient_weight,
+            emitter_weight=pl.emitter_weight, grid_spacing=pl.grid_spacing, enable_divergence=pl.enable_divergence,
+            enable_gradient=pl.enable_gradient, enable_emitter=pl.enable_emitter, padding_mode=config.padding_mode,
+            stencil_mode=pl.stencil_mode)
+        self.optimizer = FusedClipAdam(model, config.learning_rate, config.gradient_clip_norm if config.gradient_clip_enabled else None)
+        self.scaler = None                                   # bf16 storage / fp32 accumulate needs no loss scaling
+        self.scheduler = _Scheduler(self.optimizer, config) if config.use_lr_scheduler else None
+        ckdir = Path(config.checkpoint_dir) / str(getattr(model, "model_name", "Unet"))
+        self.early_stopping = EarlyStopping(config.early_stop_patience, config.early_stop_min_delta, ckdir) if config.use_early_stopping else None
+        self.config.checkpoint_dir = ckdir
+        ckdir.mkdir(parents=True, exist_ok=True)
+        self.history: Dict[str, list] = {"train_total": [], "train_mse": [], "val_total": [], "val_mse": [], "learning_rate": []}
+        self._plans: Dict[Tuple, RolloutTrainPlan] = {}
+        self._dist = None
+        try:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                self._dist = dist
+        except Exception:
+            self._dist = None
+
+    # ------------------------------------------------------------------ the K-step rollout loss, literal loop
+    def _compute_rollout_loss(self, x_0: torch.Tensor, y_seq: torch.Tensor, masks: torch.Tensor):
+        """ml/training/trainer.py:311-385."""
+        K = y_seq.shape[1]
+        cfg = self.config
+        state_current, state_prev = x_0[:, :3], x_0[:, 3:4]
+        if cfg.rollout_final_step_only:
+            for k in range(K):
+                model_input = torch.cat([state_current, state_prev, masks[:, k, 0:1], masks[:, k, 1:2]], dim=1)
+                pred = self.model(model_input)
+                if k == K - 1:
+                    loss, d = self.criterion(pred, y_seq[:, k], model_input)
+                    return loss, d, pred
+                if cfg.rollout_gradient_truncation:
+                    state_prev, state_current = pred[:, 0:1].detach(), pred.detach()
+                else:
+                    state_prev, state_current = pred[:, 0:1], pred
+            raise RuntimeError("Should have returned on final step")
+        total = torch.zeros((), device=x_0.device)
+        acc: Dict[str, float] = {}
+        wsum = 0.0
+        pred = None
+        for k in range(K):
+            model_input = torch.cat([state_current, state_prev, masks[:, k, 0:1], masks[:, k, 1:2]], dim=1)
+            pred = self.model(model_input)
+            loss_k, d_k = self.criterion(pred, y_seq[:, k], model_input)
+            w = cfg.rollout_weight_decay ** k
+            total = total + w * loss_k
+            wsum += w
+            for key, val in d_k.items():
+                acc[key] = acc.get(key, 0.0) + w * val
+            if cfg.rollout_gradient_truncation:
+                state_prev, state_current = pred[:, 0:1].detach(), pred.detach()
+            else:
+                state_prev, state_current = pred[:, 0:1], pred
+        return total / wsum, {k: v / wsum for k, v in acc.items()}, pred
+
+    # ------------------------------------------------------------------ native step
+    def _plan_for(self, B: int, H: int, W: int, K: int, mask_frames: int) -> Optional[RolloutTrainPlan]:
+        key = (B, H, W, K, mask_frames)
+        p = self._plans.get(key)
+        if p is None and len(self._plans) < self.max_plans:
+            cfg = self.config
+            world = self._dist.get_world_size() if self._dist is not None else 1
+            p = RolloutTrainPlan(self.model.cfg, self.criterion, B, H, W, K, dtype=self.model.precision, conv_impl=self.model.conv_impl,
+                                 weight_decay=cfg.rollout_weight_decay, gradient_truncation=cfg.rollout_gradient_truncation,
+                                 final_step_only=cfg.rollout_final_step_only, mask_frames=mask_frames, world=world,
+                                 clip_norm=self.gradient_clip_norm if self.gradient_clip_enabled else None,
+                                 betas=self.optimizer.betas, eps=self.optimizer.eps, seed=self.model.seed)
+            # one Adam state for every shape: the plans share the optimizer's moment buffers
+            _, _, m, v, _ = self.optimizer._state()
+            p.bind(self.model.flat_params.device, self.model.flat_params, self.model.flat_grads, adam_m=m, adam_v=v)
+            self._plans[key] = p
+        return p
+
+    def _native_step(self, inputs: torch.Tensor, targets: torch.Tensor, masks: Optional[torch.Tensor]) -> Optional[Dict[str, float]]:
+        B, _, H, W = inputs.shape
+        if masks is None:                       # single-step batch (x, y): K = 1, masks are channels 4,5 of x (trainer.py:187-188)
+            targets = targets[:, None]
+            masks = inputs[:, None, 4:6]
+        K, Km = targets.shape[1], masks.shape[1]
+        plan = self._plan_for(B, H, W, K, Km)
+        if plan is None:
+            return None
+        plan.x0.tensor.copy_(inputs)
+        plan.y.tensor.copy_(targets)
+        plan.masks.tensor.copy_(masks)
+        self.optimizer.step_count += 1
+        plan.set_adam_scalars(self.optimizer.param_groups[0]["lr"], self.optimizer.step_count)
+        plan.set_dropout_seed(self.optimizer.step_count * 7919 + 13)
+        world = self._dist.get_world_size() if self._dist is not None else 1
+        dp_train_step(plan, world, torch_all_reduce(self._dist) if world > 1 else None)
+        self.model.flat_params.add_(0)          # bump the autograd version: autograd-path engines refresh their bf16 weights
+        return plan.loss_dict()
+
+    # ------------------------------------------------------------------ epoch loops
+    def _to_device(self, batch):
+        return tuple(t.to(self.device, non_blocking=True) for t in batch)
+
+    def train_epoch(self) -> Dict[str, float]:
+        self.model.train()
+        acc: Dict[str, float] = {}
+        n = 0
+        for batch in self.train_loader:
+            batch = self._to_device(batch)
+            rollout = len(batch) == 3
+            inputs, targets = batch[0], batch[1]
+            masks = batch[2] if rollout else None
+            d = self._native_step(inputs, targets, masks) if self.engine == "plan" else None
+            if d is None:
+                self.optimizer.zero_grad()
+                if rollout:
+                    loss, d, _ = self._compute_rollout_loss(inputs, targets, masks)
+                else:
+                    outputs = self.model(inputs)
+                    loss, d = self.criterion(outputs, targets, inputs)
+                loss.backward()
+                self.optimizer.step()
+            n += 1
+            for k, v in d.items():
+                acc[k] = acc.get(k, 0.0) + v
+        return {k: v / max(n, 1) for k, v in acc.items()}
+
+    def validate(self) -> Dict[str, float]:
+        self.model.eval()
+        acc: Dict[str, float] = {}
+        n = 0
+        with torch.no_grad():
+            for batch in self.val_loader:
+                batch = self._to_device(batch)
+                if len(batch) == 3:
+                    _, d, _ = self._compute_rollout_loss(*batch)
+                else:
+                    outputs = self.model(batch[0])
+                    _, d = self.criterion(outputs, batch[1], batch[0])
+                n += 1
+                for k, v in d.items():
+                    acc[k] = acc.get(k, 0.0) + v
+        return {k: v / max(n, 1) for k, v in acc.items()}
+
+    def train(self) -> None:
+        for epoch in range(self.config.epochs):
+            t0 = time.time()
+            ds = getattr(self.train_loader, "dataset", None)
+            if hasattr(ds, "set_epoch"):
+                ds.set_epoch(epoch)
+            tr = self.train_epoch()
+            va = self.validate()
+            lr = self.optimizer.param_groups[0]["lr"]
+            self.history["train_total"].append(tr["total"])
+            self.history["train_mse"].append(tr.get("mse", 0.0))
+            self.history["val_total"].append(va["total"])
+            self.history["val_mse"].append(va.get("mse", 0.0))
+            self.history["learning_rate"].append(lr)
+            print(f"Epoch {epoch + 1}/{self.config.epochs} | Train Loss: {tr['total']:.6f} | Val Loss: {va['total']:.6f} | "
+                  f"Time: {time.time() - t0:.2f}s")
+            if self.scheduler is not None:
+                self.scheduler.step(va["total"])
+            if self.early_stopping is not None:
+                if self.early_stopping(va["total"], epoch):
+                    self.early_stopping.save_checkpoint(self.model, self.optimizer, None, self.config, epoch)
+                    break
+                if self.early_stopping.counter == 0:
+                    self.early_stopping.save_checkpoint(self.model, self.optimizer, None, self.config, epoch)
+            if (epoch + 1) % self.config.save_every_n_epochs == 0:
+                self.save_checkpoint(epoch)
+        if self.early_stopping is not None:
+            self.early_stopping.load_best_checkpoint(self.model, self.optimizer, None, self.device)
+        else:
+            self.save_checkpoint(self.config.epochs - 1, final=True)
+
+    # ------------------------------------------------------------------ checkpoints (trainer.py:717-784)
+    def save_checkpoint(self, epoch: int, final: bool = False) -> None:
+        ck: Dict[str, Any] = {"epoch": epoch, "model_state_dict": {k: v.detach().cpu() for k, v in self.model.state_dict().items()},
+                              "optimizer_state_dict": self.optimizer.state_dict(), "config": self.config.model_dump(mode="json")}
+        if self.scheduler is not None:
+            ck["scheduler_state_dict"] = self.scheduler.state_dict()
+        if self.early_stopping is not None:
+            ck["early_stopping_state"] = self.early_stopping.state_dict()
+        path = self.config.checkpoint_dir / ("final_model.pth" if final else f"checkpoint_epoch_{epoch + 1}.pth")
+        torch.save(ck, path)
+        if not final:
+            cks = sorted(self.config.checkpoint_dir.glob("checkpoint_epoch_*.pth"), key=lambda x: x.stat().st_mtime)
+            while len(cks) > self.config.keep_last_n_checkpoints:
+                cks.pop(0).unlink()
+
+    def load_checkpoint(self, checkpoint_path) -> int:
+        ck = torch.load(Path(checkpoint_path), map_location=self.device, weights_only=True)
+        self.model.load_state_dict(ck["model_state_dict"])
+        self.optimizer.load_state_dict(ck["optimizer_state_dict"])
+        if self.scheduler is not None and "scheduler_state_dict" in ck:
+            self.scheduler.load_state_dict(ck["scheduler_state_dict"])
+        if self.early_stopping is not None and "early_stopping_state" in ck:
+            self.early_stopping.load_state_dict(ck["early_stopping_state"])
+        return int(ck.get("epoch", 0))

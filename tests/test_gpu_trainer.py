@@ -1,0 +1,107 @@
+"""Trainer / dataset / inference-backend drop-in API on the GPU: a tiny UNet trained for a few steps from a synthetic
+seq_*.npz set, native-plan engine vs the autograd engine vs the CPU oracle's train_step."""
+import numpy as np
+import pytest
+import torch
+from torch.utils.data import DataLoader
+
+import fluidnet_oracle as orc
+from fluidnet_amd.config.training_config import PhysicsLossConfig, TrainingConfig
+from fluidnet_amd.dataset.npz_sequence import FluidNPZSequenceDataset
+from fluidnet_amd.inference.backend import PyTorchBackend
+from fluidnet_amd.models.unet import UNet, UNetConfig
+from fluidnet_amd.training.trainer import Trainer
+from helpers import tiny_cfg
+
+pytestmark = pytest.mark.gpu
+
+
+def _npz(tmp_path, n_seq=2, T=8, R=32):
+    rs = np.random.RandomState(3)
+    for split in ("train", "val"):
+        d = tmp_path / "npz" / split
+        d.mkdir(parents=True)
+        for i in range(n_seq):
+            x0, y, mk = orc.synth_batch(T, 1, R, seed=10 * i + (0 if split == "train" else 5))
+            np.savez_compressed(d / f"seq_{i:04d}.npz", density=x0[:, 0], velx=x0[:, 1], velz=x0[:, 2], emitter=np.repeat(mk[:1, 0, 0], T, 0),
+                                collider=np.repeat(mk[:1, 0, 1], T, 0))
+    return tmp_path / "npz"
+
+
+def _config(tmp_path, K):
+    return TrainingConfig(batch_size=2, learning_rate=1e-3, epochs=1, device="cuda", npz_dir=tmp_path / "npz", normalize=False,
+                          base_channels=8, depth=2, checkpoint_dir=tmp_path / "ck", rollout_step=K, use_early_stopping=True,
+                          physics_loss=PhysicsLossConfig(divergence_weight=0.01, gradient_weight=0.001, emitter_weight=0.01,
+                                                         enable_divergence=True, enable_gradient=True, enable_emitter=True,
+                                                         grid_spacing=2.0 / 32))
+
+
+def _model(precision="fp32"):
+    cfg = tiny_cfg()
+    m = UNet(UNetConfig(**cfg.__dict__), precision=precision)
+    m.load_state_dict(orc.make_params(cfg, seed=4))
+    return m.to("cuda"), cfg
+
+
+@pytest.mark.parametrize("K", [1, 3])
+def test_plan_engine_matches_autograd_engine_and_oracle(tmp_path, K):
+    root = _npz(tmp_path)
+    cfgT = _config(tmp_path, K)
+    ds = FluidNPZSequenceDataset(root, "train", rollout_steps=K, preload=True, stride=1)
+    batches = [next(iter(DataLoader(ds, batch_size=2, shuffle=False)))]
+    outs = {}
+    for engine in ("plan", "autograd"):
+        model, cfg = _model()
+        tr = Trainer(model, batches, batches, cfgT, "cuda", engine=engine)
+        d1 = tr.train_epoch()
+        d2 = tr.train_epoch()
+        outs[engine] = (d1, d2, model.flat_params.detach().cpu().clone())
+    # oracle: two Adam steps on the same batch
+    cfg = tiny_cfg()
+    p = {k: v.clone() for k, v in orc.make_params(cfg, seed=4).items()}
+    m = {k: torch.zeros_like(v) for k, v in p.items()}
+    v = {k: torch.zeros_like(t) for k, t in p.items()}
+    lc = orc.LossConfig(1.0, 0.01, 0.001, 0.01, 2.0 / 32, True, True, True, "replicate", "forward")
+    b = batches[0]
+    if K == 1:
+        x0, y, mk = b[0], b[1][:, None], b[0][:, None, 4:6]
+    else:
+        x0, y, mk = b
+    losses = []
+    for step in (1, 2):
+        loss, _, _ = orc.train_step(p, m, v, step, cfg, lc, x0, y, mk, lr=1e-3, clip_norm=1.0)
+        losses.append(float(loss))
+    for engine in ("plan", "autograd"):
+        d1, d2, _ = outs[engine]
+        assert set(d1) == {"mse", "divergence", "gradient", "emitter", "total"}
+        assert abs(d1["total"] - losses[0]) < 2e-5 * max(1, abs(losses[0])), (engine, d1["total"], losses[0])
+        assert abs(d2["total"] - losses[1]) < 2e-3 * max(1, abs(losses[1])), (engine, d2["total"], losses[1])
+    assert (outs["plan"][2] - outs["autograd"][2]).abs().max() < 2e-3       # Adam amplifies noise-level gradient elements up to lr per step
+    assert d2["total"] < d1["total"] * 1.5
+
+
+def test_train_loop_checkpoint_and_backend(tmp_path):
+    root = _npz(tmp_path)
+    cfgT = _config(tmp_path, 2)
+    tr_ds = FluidNPZSequenceDataset(root, "train", rollout_steps=2, preload=True, stride=2, is_training=True,
+                                    augmentation_config={"enable_augmentation": True, "flip_probability": 0.5})
+    va_ds = FluidNPZSequenceDataset(root, "val", rollout_steps=2, preload=False)
+    model, _ = _model("bf16")
+    tr = Trainer(model, DataLoader(tr_ds, batch_size=2, shuffle=True, drop_last=True), DataLoader(va_ds, batch_size=2), cfgT, "cuda")
+    tr.train()
+    assert len(tr.history["train_total"]) == 1 and np.isfinite(tr.history["val_total"][0])
+    best = tr.config.checkpoint_dir / "best_model.pth"
+    assert best.exists()
+    ck = torch.load(best, weights_only=True)
+    assert set(ck) >= {"epoch", "model_state_dict", "optimizer_state_dict", "config", "val_loss"}
+    assert list(ck["model_state_dict"].keys()) == list(model.state_dict().keys())
+    be = PyTorchBackend()
+    be.load_model(best, "cuda")
+    x = np.random.RandomState(0).rand(1, 6, 32, 32).astype(np.float32)
+    out = be.infer(x)
+    assert out.shape == (1, 3, 32, 32) and out.dtype == np.float32 and np.isfinite(out).all()
+    with torch.no_grad():
+        ref = model.eval()(torch.from_numpy(x).cuda()).cpu().numpy()
+    np.testing.assert_allclose(out, ref, atol=1e-6)
+    tr.save_checkpoint(0)
+    assert tr.load_checkpoint(tr.config.checkpoint_dir / "checkpoint_epoch_1.pth") == 0

@@ -10,6 +10,12 @@
 
 int g_fnet_last_hip_error = 0;
 
+#ifndef FNET_EW_U
+#define FNET_EW_U 1
+#endif
+#ifndef FNET_EW_UR
+#define FNET_EW_UR 2
+#endif
 namespace {
 
 constexpr int kThreads = 256;
@@ -126,13 +132,25 @@ __global__ __launch_bounds__(256) void k_in_stats_part(const T* raw, float* part
         const T* base = raw + (size_t)n * (H + 2) * Wp * ldc + coff + m.cg * 8;
         int q = q0 + m.px;
         int y = q / W, x = q - y * W;
-        for (; q < q1; q += m.ppi) {
-            Vec8<T> v;
-            v.load(base + ((size_t)(y + 1) * Wp + (x + 1)) * ldc);
+        // U pixels per trip, all loads issued before the arithmetic: with one 16-B load in flight per thread the kernels
+        // of this family were latency-bound (32 KB in flight per CU ~ 4 TB/s)
+        constexpr int U = FNET_EW_U;
+        for (; q < q1; q += U * m.ppi) {
+            Vec8<T> v[U];
+            bool ok[U];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) { s[k] += v.v[k]; t[k] = fmaf(v.v[k], v.v[k], t[k]); }
-            x += m.ppi;
-            while (x >= W) { x -= W; ++y; }
+            for (int u = 0; u < U; ++u) {
+                ok[u] = q + u * m.ppi < q1;
+                if (ok[u]) v[u].load(base + ((size_t)(y + 1) * Wp + (x + 1)) * ldc);
+                x += m.ppi;
+                while (x >= W) { x -= W; ++y; }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (ok[u]) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) { s[k] += v[u].v[k]; t[k] = fmaf(v[u].v[k], v[u].v[k], t[k]); }
+                }
         }
     }
 #pragma unroll
@@ -184,7 +202,7 @@ __global__ __launch_bounds__(256) void k_in_finalize_tiles(const float2* part, f
 // ------------------------------------------------------------------ APPLY
 // dst[n,y,x,c] = act(gamma*(raw[src]-mean)*rstd+beta) * drop(n,c) + res[src], over the padded domain
 template <typename T, int ACT>
-__global__ __launch_bounds__(256) void k_apply(const T* raw, const float2* stats, const float* gamma, const float* beta, const T* res, T* dst,
+__global__ __launch_bounds__(256) void k_apply(const T* __restrict__ raw, const float2* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta, const T* __restrict__ res, T* __restrict__ dst,
                         int H, int W, int C, int ldc_raw, int coff_raw, int ldc_res, int coff_res, int ldc_dst,
                         int coff_dst, int act, int pm, uint32_t site, uint32_t seed, float drop_p, int p_per_block) {
     const CgMap m(C);
@@ -207,28 +225,43 @@ __global__ __launch_bounds__(256) void k_apply(const T* raw, const float2* stats
     T* dbase = dst + img * ldc_dst + coff_dst + c0;
     int p = p0 + m.px;
     int y = p / Wp, x = p - y * Wp;
-    for (; p < p1; p += m.ppi) {
-        const int sy = pad_src(y - 1, H, pm), sx = pad_src(x - 1, W, pm);
-        Vec8<T> o;
-        if (sy < 0 || sx < 0) {
+    constexpr int U = FNET_EW_U;       // pixels per trip: all loads first (see k_in_stats_part)
+    for (; p < p1; p += U * m.ppi) {
+        Vec8<T> r[U], q[U];
+        int st[U];             // 0 = past the end, 1 = zero ring pixel, 2 = computed
 #pragma unroll
-            for (int k = 0; k < 8; ++k) o.v[k] = 0.f;
-        } else {
-            const size_t sp = (size_t)(sy + 1) * Wp + sx + 1;
-            Vec8<T> r;
-            r.load(rbase + sp * ldc_raw);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) o.v[k] = act_fwd_t<ACT>(fmaf(r.v[k], ca[k], cb[k])) * dsc[k];
-            if (sbase) {
-                Vec8<T> q;
-                q.load(sbase + sp * ldc_res);
-#pragma unroll
-                for (int k = 0; k < 8; ++k) o.v[k] += q.v[k];
+        for (int u = 0; u < U; ++u) {
+            st[u] = 0;
+            if (p + u * m.ppi < p1) {
+                const int sy = pad_src(y - 1, H, pm), sx = pad_src(x - 1, W, pm);
+                st[u] = 1;
+                if (sy >= 0 && sx >= 0) {
+                    st[u] = 2;
+                    const size_t sp = (size_t)(sy + 1) * Wp + sx + 1;
+                    r[u].load(rbase + sp * ldc_raw);
+                    if (sbase) q[u].load(sbase + sp * ldc_res);
+                }
             }
+            x += m.ppi;
+            while (x >= Wp) { x -= Wp; ++y; }
         }
-        o.store(dbase + (size_t)p * ldc_dst);
-        x += m.ppi;
-        while (x >= Wp) { x -= Wp; ++y; }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (st[u] == 0) continue;
+            Vec8<T> o;
+            if (st[u] == 1) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) o.v[k] = 0.f;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) o.v[k] = act_fwd_t<ACT>(fmaf(r[u].v[k], ca[k], cb[k])) * dsc[k];
+                if (sbase) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) o.v[k] += q[u].v[k];
+                }
+            }
+            o.store(dbase + (size_t)(p + u * m.ppi) * ldc_dst);
+        }
     }
 }
 
@@ -260,8 +293,8 @@ __device__ __forceinline__ void fold_read8(const T* g, int n, int y, int x, int 
 // G = fold(g1) + fold(g2); dz = G*drop*act'(u); S1 = sum dz, S2 = sum dz*xhat per (n,c).  Writes G (interior) and adds the
 // block's partial sums into S (zeroed by the plan before this op).
 template <typename T, int ACT>
-__global__ __launch_bounds__(256) void k_inact_bwd_reduce(const T* g1, const T* g2, const T* raw, const float2* stats, const float* gamma,
-                                   const float* beta, T* G, float* S, float* dgamma, float* dbeta, int H, int W, int C, int ldc_g1,
+__global__ __launch_bounds__(256) void k_inact_bwd_reduce(const T* __restrict__ g1, const T* __restrict__ g2, const T* __restrict__ raw, const float2* __restrict__ stats, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, T* __restrict__ G, float* __restrict__ S, float* dgamma, float* dbeta, int H, int W, int C, int ldc_g1,
                                    int coff_g1, int ldc_g2, int coff_g2, int ldc_raw, int coff_raw, int ldc_G, int coff_G,
                                    int fold1, int fold2, int act, int pm, uint32_t site, uint32_t seed, float drop_p, int q_per_block) {
     __shared__ float red[kThreads * 16];
@@ -285,32 +318,45 @@ __global__ __launch_bounds__(256) void k_inact_bwd_reduce(const T* g1, const T* 
         T* Gbase = G + img * ldc_G + coff_G + c0;
         int q = q0 + m.px;
         int y = q / W, x = q - y * W;
-        for (; q < q1; q += m.ppi) {
-            float acc[8];
+        constexpr int U = FNET_EW_UR;   // pixels per trip: gradient and activation loads of both pixels are issued before the arithmetic
+        for (; q < q1; q += U * m.ppi) {
+            float acc[U][8];
+            Vec8<T> r[U];
+            size_t pix[U];
+            bool ok[U];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) acc[k] = 0.f;
-            fold_read8<T>(g1 + coff_g1 + c0, n, y, x, H, W, ldc_g1, pm, fold1, acc);
-            if (g2) fold_read8<T>(g2 + coff_g2 + c0, n, y, x, H, W, ldc_g2, pm, fold2, acc);
-            const size_t pix = (size_t)(y + 1) * Wp + x + 1;
-            Vec8<T> go;
+            for (int u = 0; u < U; ++u) {
+                ok[u] = q + u * m.ppi < q1;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) go.v[k] = acc[k];
-            go.store(Gbase + pix * ldc_G);
-            Vec8<T> r;
-            r.load(rbase + pix * ldc_raw);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                // use the value as stored (bf16-rounded in bf16 mode) so that pass 2 sees the same G
-                const float xh = fmaf(r.v[k], xa[k], xb[k]);
-                const float u = fmaf(xh, gam[k], bet[k]);
-                float gq = go.v[k];
-                if (sizeof(T) == 2) gq = bf2f(f2bf(gq));
-                const float dz = gq * dsc[k] * act_bwd_t<ACT>(u);
-                s[k] += dz;
-                t[k] = fmaf(dz, xh, t[k]);
+                for (int k = 0; k < 8; ++k) acc[u][k] = 0.f;
+                if (ok[u]) {
+                    fold_read8<T>(g1 + coff_g1 + c0, n, y, x, H, W, ldc_g1, pm, fold1, acc[u]);
+                    if (g2) fold_read8<T>(g2 + coff_g2 + c0, n, y, x, H, W, ldc_g2, pm, fold2, acc[u]);
+                    pix[u] = (size_t)(y + 1) * Wp + x + 1;
+                    r[u].load(rbase + pix[u] * ldc_raw);
+                }
+                x += m.ppi;
+                while (x >= W) { x -= W; ++y; }
             }
-            x += m.ppi;
-            while (x >= W) { x -= W; ++y; }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (!ok[u]) continue;
+                Vec8<T> go;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) go.v[k] = acc[u][k];
+                go.store(Gbase + pix[u] * ldc_G);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    // use the value as stored (bf16-rounded in bf16 mode) so that pass 2 sees the same G
+                    const float xh = fmaf(r[u].v[k], xa[k], xb[k]);
+                    const float uu = fmaf(xh, gam[k], bet[k]);
+                    float gq = go.v[k];
+                    if (sizeof(T) == 2) gq = bf2f(f2bf(gq));
+                    const float dz = gq * dsc[k] * act_bwd_t<ACT>(uu);
+                    s[k] += dz;
+                    t[k] = fmaf(dz, xh, t[k]);
+                }
+            }
         }
     }
 #pragma unroll
@@ -331,8 +377,8 @@ __global__ __launch_bounds__(256) void k_inact_bwd_reduce(const T* g1, const T* 
 // d_raw = gamma*rstd*(dz - S1/HW - xhat*S2/HW) on the interior, 0 on the ring (so that d_raw can feed
 // the flattened dgrad / wgrad convolutions directly).
 template <typename T, int ACT>
-__global__ __launch_bounds__(256) void k_inact_bwd_apply(const T* G, const T* raw, const float2* stats, const float* gamma, const float* beta,
-                                  const float2* S, T* draw, int H, int W, int C, int ldc_G, int coff_G, int ldc_raw,
+__global__ __launch_bounds__(256) void k_inact_bwd_apply(const T* __restrict__ G, const T* __restrict__ raw, const float2* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                  const float2* __restrict__ S, T* __restrict__ draw, int H, int W, int C, int ldc_G, int coff_G, int ldc_raw,
                                   int coff_raw, int ldc_d, int coff_d, int act, uint32_t site, uint32_t seed, float drop_p,
                                   int p_per_block) {
     const CgMap m(C);
@@ -358,26 +404,42 @@ __global__ __launch_bounds__(256) void k_inact_bwd_apply(const T* G, const T* ra
     T* dbase = draw + img * ldc_d + coff_d + c0;
     int p = p0 + m.px;
     int y = p / Wp, x = p - y * Wp;
-    for (; p < p1; p += m.ppi) {
-        Vec8<T> o;
-        if (y == 0 || y == Hp - 1 || x == 0 || x == Wp - 1) {
+    constexpr int U = FNET_EW_U;       // pixels per trip: all loads first (see k_in_stats_part)
+    for (; p < p1; p += U * m.ppi) {
+        Vec8<T> g[U], r[U];
+        int st[U];             // 0 = past the end, 1 = ring pixel (zero), 2 = interior
 #pragma unroll
-            for (int k = 0; k < 8; ++k) o.v[k] = 0.f;
-        } else {
-            Vec8<T> g, r;
-            g.load(Gbase + (size_t)p * ldc_G);
-            r.load(rbase + (size_t)p * ldc_raw);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const float xh = fmaf(r.v[k], xa[k], xb[k]);
-                const float u = fmaf(xh, gam[k], bet[k]);
-                const float dz = g.v[k] * dsc[k] * act_bwd_t<ACT>(u);
-                o.v[k] = k0[k] * (dz - k1[k] - xh * k2[k]);
+        for (int u = 0; u < U; ++u) {
+            st[u] = 0;
+            const int pu = p + u * m.ppi;
+            if (pu < p1) {
+                st[u] = (y == 0 || y == Hp - 1 || x == 0 || x == Wp - 1) ? 1 : 2;
+                if (st[u] == 2) {
+                    g[u].load(Gbase + (size_t)pu * ldc_G);
+                    r[u].load(rbase + (size_t)pu * ldc_raw);
+                }
             }
+            x += m.ppi;
+            while (x >= Wp) { x -= Wp; ++y; }
         }
-        o.store(dbase + (size_t)p * ldc_d);
-        x += m.ppi;
-        while (x >= Wp) { x -= Wp; ++y; }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (st[u] == 0) continue;
+            Vec8<T> o;
+            if (st[u] == 1) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) o.v[k] = 0.f;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float xh = fmaf(r[u].v[k], xa[k], xb[k]);
+                    const float uu = fmaf(xh, gam[k], bet[k]);
+                    const float dz = g[u].v[k] * dsc[k] * act_bwd_t<ACT>(uu);
+                    o.v[k] = k0[k] * (dz - k1[k] - xh * k2[k]);
+                }
+            }
+            o.store(dbase + (size_t)(p + u * m.ppi) * ldc_d);
+        }
     }
 }
 

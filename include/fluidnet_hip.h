@@ -68,7 +68,7 @@ extern "C" {
 /* ---- op records ------------------------------------------------------------------------
  * A "plan" is an array of FnetOp executed in order on one stream by fnet_plan_run().  The host
  * side (fluidnet_amd/engine/plan.py) builds one plan per (UNetConfig, B, H, W, K) and replays
- * it every step; slot meaning per opcode is documented in fluidnet_amd/csrc/fnet_ops.h.
+ * it every step; slot meaning per opcode is documented in include/fluidnet_ops.h.
  */
 typedef struct FnetOp {
     int32_t op;       /* FNET_OP_* */

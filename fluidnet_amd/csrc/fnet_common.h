@@ -21,6 +21,9 @@ __device__ __forceinline__ uint32_t f2bf_pk(float lo, float hi) {
 }
 
 // 8-channel vector load/store for P-tensors (C % 8 == 0, channel offsets % 8 == 0)
+#ifndef FNET_NT_STORE
+#define FNET_NT_STORE 0
+#endif
 template <typename T>
 struct Vec8;
 template <>
@@ -34,6 +37,16 @@ struct Vec8<float> {
     __device__ __forceinline__ void store(float* p) const {
         *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
         *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+    // streaming store: the consumer is a later kernel, so the lines need not stay in (and later be flushed from) this XCD's L2
+    __device__ __forceinline__ void store_nt(float* p) const {
+#if FNET_NT_STORE
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        __builtin_nontemporal_store((f32x4){v[0], v[1], v[2], v[3]}, reinterpret_cast<f32x4*>(p));
+        __builtin_nontemporal_store((f32x4){v[4], v[5], v[6], v[7]}, reinterpret_cast<f32x4*>(p + 4));
+#else
+        store(p);
+#endif
     }
 };
 template <>
@@ -54,7 +67,28 @@ struct Vec8<bf16_t> {
         for (int k = 0; k < 4; ++k) w[k] = f2bf_pk(v[2 * k], v[2 * k + 1]);
         *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
     }
+    __device__ __forceinline__ void store_nt(bf16_t* p) const {
+#if FNET_NT_STORE
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        uint32_t w[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) w[k] = f2bf_pk(v[2 * k], v[2 * k + 1]);
+        __builtin_nontemporal_store((u32x4){w[0], w[1], w[2], w[3]}, reinterpret_cast<u32x4*>(p));
+#else
+        store(p);
+#endif
+    }
 };
+
+// 16-byte streaming store of an already packed vector (convolution epilogue)
+__device__ __forceinline__ void st_stream16(bf16_t* p, const uint4& v) {
+#if FNET_NT_STORE
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    __builtin_nontemporal_store((u32x4){v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4*>(p));
+#else
+    *reinterpret_cast<uint4*>(p) = v;
+#endif
+}
 
 template <typename T>
 __device__ __forceinline__ float ld1(const T* p);

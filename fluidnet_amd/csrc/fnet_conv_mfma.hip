@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_dma(const bf16_t* __restrict
                     const long long f = f0 + px;
                     if (f < Npix) {
                         const uint4 v = *reinterpret_cast<const uint4*>(ot + px * PO + (((chunk ^ px) & (CH - 1)) << 4));
-                        *reinterpret_cast<uint4*>(dst + (size_t)f * ldc_out + coff_out + n0 + chunk * 8) = v;
+                        st_stream16(dst + (size_t)f * ldc_out + coff_out + n0 + chunk * 8, v);
                     }
                 }
             }
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_dma(const bf16_t* __restrict
                 const long long f = f0 + px;
                 if (f < Npix && cvalid) {
                     const uint4 v = *reinterpret_cast<const uint4*>(ot + px * PO + (((chunk ^ px) & (CH - 1)) << 4));
-                    *reinterpret_cast<uint4*>(dst + (size_t)f * ldc_out + coff_out + n0 + chunk * 8) = v;
+                    st_stream16(dst + (size_t)f * ldc_out + coff_out + n0 + chunk * 8, v);
                     if (y >= 1 && y <= H && x >= 1 && x <= W) {
                         const uint32_t w[4] = {v.x, v.y, v.z, v.w};
                         const bool second = n != n_first;

@@ -6,15 +6,20 @@
 // image is walked by consecutive lanes so global accesses coalesce (cdna guide G2/G13).
 // Grid convention for "row kernels": blockIdx.x = n*(H+2)+y (one padded row), blockIdx.y*256+tid
 // = x*(C/8)+cg within the row.
+#include <cstdlib>
 #include "fnet_common.h"
 
 int g_fnet_last_hip_error = 0;
 
+// pixels per loop trip of the channel-group kernels (forward/backward apply, backward reduce, statistics)
 #ifndef FNET_EW_U
-#define FNET_EW_U 1
+#define FNET_EW_U 2
 #endif
 #ifndef FNET_EW_UR
 #define FNET_EW_UR 2
+#endif
+#ifndef FNET_EW_US
+#define FNET_EW_US 4
 #endif
 namespace {
 
@@ -73,7 +78,38 @@ struct CgMap {
         px = threadIdx.x / groups;
         active = px < ppi;
     }
+    // This thread's pixel sequence first, first+stride, ... < end: the block owns pixels [blockIdx.x*per_block, +per_block) of
+    // an image of n_pix pixels.  (Interleaving an image's blocks so that they sweep one window together was measured and
+    // made no difference; fewer, longer blocks did: see cg_pixels_per_block.)
+    __device__ __forceinline__ void range(int n_pix, int per_block, int& first, int& stride, int& end) const {
+        const int p0 = blockIdx.x * per_block;
+        first = p0 + px; stride = ppi; end = min(n_pix, p0 + per_block);
+    }
 };
+
+// Walks pixel indices p, p+stride, p+2*stride, ... of rows of length L as (y, x) without a division or a branch per step
+// (the stride is split into whole rows + columns once).  The cg kernels issue the loads of U pixels back to back, so the
+// address arithmetic between them must not contain branches, or hipcc waits for each load before the next.
+struct PixWalk {
+    int y, x, sy, sx, L;
+    __device__ __forceinline__ PixWalk(int p, int stride, int L_) : L(L_) {
+        y = p / L; x = p - y * L;
+        sy = stride / L; sx = stride - sy * L;
+    }
+    __device__ __forceinline__ void step() {
+        x += sx; y += sy;
+        const bool w = x >= L;
+        x = w ? x - L : x;
+        y = w ? y + 1 : y;
+    }
+};
+template <int N> struct IntC { static constexpr int value = N; };
+// v or +0.0 by bit mask (keep = 0xffffffff / 0): a select that the compiler cannot turn back into a branch around the
+// arithmetic that produced v, and that also kills a NaN/Inf computed from an unwritten ring pixel
+__device__ __forceinline__ float keep_bits(float v, uint32_t keep) { return __uint_as_float(__float_as_uint(v) & keep); }
+// pad_src for i in [-1, n] with the out-of-range results hoisted (lo = source of -1, hi = source of n; -1 = zero padding)
+__device__ __forceinline__ int pad_lo(int n, int pm) { return pm == FNET_PAD_REPLICATE ? 0 : pm == FNET_PAD_REFLECT ? 1 : pm == FNET_PAD_CIRCULAR ? n - 1 : -1; }
+__device__ __forceinline__ int pad_hi(int n, int pm) { return pm == FNET_PAD_REPLICATE ? n - 1 : pm == FNET_PAD_REFLECT ? n - 2 : pm == FNET_PAD_CIRCULAR ? 0 : -1; }
 
 // ------------------------------------------------------------------ IN_STATS
 // fp32 plans: one block per (n, 8-channel group), exact two-pass mean / biased variance over the interior H*W
@@ -124,34 +160,31 @@ __global__ __launch_bounds__(256) void k_in_stats_part(const T* raw, float* part
     __shared__ float red[kThreads * 16];
     const CgMap m(C);
     const int n = blockIdx.y, HW = H * W, Wp = W + 2;
-    const int q0 = blockIdx.x * q_per_block, q1 = min(HW, q0 + q_per_block);
+    int q, qs, q1;
+    m.range(HW, q_per_block, q, qs, q1);
     float s[8], t[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) { s[k] = 0.f; t[k] = 0.f; }
     if (m.active) {
         const T* base = raw + (size_t)n * (H + 2) * Wp * ldc + coff + m.cg * 8;
-        int q = q0 + m.px;
-        int y = q / W, x = q - y * W;
-        // U pixels per trip, all loads issued before the arithmetic: with one 16-B load in flight per thread the kernels
-        // of this family were latency-bound (32 KB in flight per CU ~ 4 TB/s)
-        constexpr int U = FNET_EW_U;
-        for (; q < q1; q += U * m.ppi) {
-            Vec8<T> v[U];
-            bool ok[U];
+        PixWalk w(q, qs, W);
+        auto trip = [&](auto uc) {
+            constexpr int UU = decltype(uc)::value;
+            Vec8<T> v[UU];
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                ok[u] = q + u * m.ppi < q1;
-                if (ok[u]) v[u].load(base + ((size_t)(y + 1) * Wp + (x + 1)) * ldc);
-                x += m.ppi;
-                while (x >= W) { x -= W; ++y; }
+            for (int u = 0; u < UU; ++u) {
+                v[u].load(base + ((size_t)(w.y + 1) * Wp + (w.x + 1)) * ldc);
+                w.step();
             }
 #pragma unroll
-            for (int u = 0; u < U; ++u)
-                if (ok[u]) {
+            for (int u = 0; u < UU; ++u) {
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) { s[k] += v[u].v[k]; t[k] = fmaf(v[u].v[k], v[u].v[k], t[k]); }
-                }
-        }
+                for (int k = 0; k < 8; ++k) { s[k] += v[u].v[k]; t[k] = fmaf(v[u].v[k], v[u].v[k], t[k]); }
+            }
+        };
+        constexpr int U = FNET_EW_US;
+        for (; q + (U - 1) * qs < q1; q += U * qs) trip(IntC<U>{});
+        for (; q < q1; q += qs) trip(IntC<1>{});
     }
 #pragma unroll
     for (int k = 0; k < 8; ++k) { red[threadIdx.x * 16 + k] = s[k]; red[threadIdx.x * 16 + 8 + k] = t[k]; }
@@ -208,7 +241,8 @@ __global__ __launch_bounds__(256) void k_apply(const T* __restrict__ raw, const 
     const CgMap m(C);
     if (!m.active) return;
     const int n = blockIdx.y, Hp = H + 2, Wp = W + 2, c0 = m.cg * 8;
-    const int p0 = blockIdx.x * p_per_block, p1 = min(Hp * Wp, p0 + p_per_block);
+    int p, ps, p1;
+    m.range(Hp * Wp, p_per_block, p, ps, p1);
     float ca[8], cb[8], dsc[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -223,45 +257,45 @@ __global__ __launch_bounds__(256) void k_apply(const T* __restrict__ raw, const 
     const T* rbase = raw + img * ldc_raw + coff_raw + c0;
     const T* sbase = res ? res + img * ldc_res + coff_res + c0 : nullptr;
     T* dbase = dst + img * ldc_dst + coff_dst + c0;
-    int p = p0 + m.px;
-    int y = p / Wp, x = p - y * Wp;
-    constexpr int U = FNET_EW_U;       // pixels per trip: all loads first (see k_in_stats_part)
-    for (; p < p1; p += U * m.ppi) {
-        Vec8<T> r[U], q[U];
-        int st[U];             // 0 = past the end, 1 = zero ring pixel, 2 = computed
+    PixWalk w(p, ps, Wp);
+    const int ylo = pad_lo(H, pm), yhi = pad_hi(H, pm), xlo = pad_lo(W, pm), xhi = pad_hi(W, pm);
+    auto trip = [&](auto uc, auto rc) {
+        constexpr int UU = decltype(uc)::value;
+        constexpr bool RES = decltype(rc)::value != 0;
+        Vec8<T> r[UU], q[UU];
+        uint32_t keep[UU];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            st[u] = 0;
-            if (p + u * m.ppi < p1) {
-                const int sy = pad_src(y - 1, H, pm), sx = pad_src(x - 1, W, pm);
-                st[u] = 1;
-                if (sy >= 0 && sx >= 0) {
-                    st[u] = 2;
-                    const size_t sp = (size_t)(sy + 1) * Wp + sx + 1;
-                    r[u].load(rbase + sp * ldc_raw);
-                    if (sbase) q[u].load(sbase + sp * ldc_res);
-                }
-            }
-            x += m.ppi;
-            while (x >= Wp) { x -= Wp; ++y; }
+        for (int u = 0; u < UU; ++u) {
+            // source pixel of padded position (y, x): itself in the interior, the padding mode's source on the ring
+            int sy = w.y - 1, sx = w.x - 1;
+            sy = sy < 0 ? ylo : (sy >= H ? yhi : sy);
+            sx = sx < 0 ? xlo : (sx >= W ? xhi : sx);
+            keep[u] = (sy | sx) < 0 ? 0u : 0xffffffffu;    // zero padding: load pixel (0,0), discard it below
+            sy = max(sy, 0); sx = max(sx, 0);
+            const size_t sp = (size_t)(sy + 1) * Wp + sx + 1;
+            r[u].load(rbase + sp * ldc_raw);
+            if (RES) q[u].load(sbase + sp * ldc_res);
+            w.step();
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (st[u] == 0) continue;
+        for (int u = 0; u < UU; ++u) {
             Vec8<T> o;
-            if (st[u] == 1) {
 #pragma unroll
-                for (int k = 0; k < 8; ++k) o.v[k] = 0.f;
-            } else {
-#pragma unroll
-                for (int k = 0; k < 8; ++k) o.v[k] = act_fwd_t<ACT>(fmaf(r[u].v[k], ca[k], cb[k])) * dsc[k];
-                if (sbase) {
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) o.v[k] += q[u].v[k];
-                }
+            for (int k = 0; k < 8; ++k) {
+                float v = act_fwd_t<ACT>(fmaf(r[u].v[k], ca[k], cb[k])) * dsc[k];
+                if (RES) v += q[u].v[k];
+                o.v[k] = keep_bits(v, keep[u]);
             }
-            o.store(dbase + (size_t)(p + u * m.ppi) * ldc_dst);
+            o.store_nt(dbase + (size_t)(p + u * ps) * ldc_dst);
         }
+    };
+    constexpr int U = FNET_EW_U;       // pixels per trip, all loads first
+    if (sbase) {
+        for (; p + (U - 1) * ps < p1; p += U * ps) trip(IntC<U>{}, IntC<1>{});
+        for (; p < p1; p += ps) trip(IntC<1>{}, IntC<1>{});
+    } else {
+        for (; p + (U - 1) * ps < p1; p += U * ps) trip(IntC<U>{}, IntC<0>{});
+        for (; p < p1; p += ps) trip(IntC<1>{}, IntC<0>{});
     }
 }
 
@@ -288,6 +322,22 @@ __device__ __forceinline__ void fold_read8(const T* g, int n, int y, int x, int 
             for (int k = 0; k < 8; ++k) acc[k] += v.v[k];
         }
 }
+// the ring copies of interior pixel (y, x) other than its own position (border pixels only): the rare half of fold_read8,
+// kept out of the way of the unconditional centre loads of the pass-1 kernel.  gimg = image base + channel offset.
+template <typename T>
+__device__ __forceinline__ void fold_extras8(const T* gimg, int y, int x, int H, int W, int ldc, int pm, float (&acc)[8]) {
+    const int Wp = W + 2;
+    int ys[3], xs[3];
+    const int ny = fold_list(y, H, pm, ys), nx = fold_list(x, W, pm, xs);
+    for (int a = 0; a < ny; ++a)
+        for (int b = 0; b < nx; ++b) {
+            if (a == 0 && b == 0) continue;               // (y+1, x+1) itself
+            Vec8<T> v;
+            v.load(gimg + ((size_t)ys[a] * Wp + xs[b]) * ldc);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[k] += v.v[k];
+        }
+}
 
 // ------------------------------------------------------------------ INACT_BWD_REDUCE (pass 1)
 // G = fold(g1) + fold(g2); dz = G*drop*act'(u); S1 = sum dz, S2 = sum dz*xhat per (n,c).  Writes G (interior) and adds the
@@ -300,7 +350,8 @@ __global__ __launch_bounds__(256) void k_inact_bwd_reduce(const T* __restrict__ 
     __shared__ float red[kThreads * 16];
     const CgMap m(C);
     const int n = blockIdx.y, Hp = H + 2, Wp = W + 2, HW = H * W, c0 = m.cg * 8;
-    const int q0 = blockIdx.x * q_per_block, q1 = min(HW, q0 + q_per_block);
+    int q, qs, q1;
+    m.range(HW, q_per_block, q, qs, q1);
     float s[8], t[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) { s[k] = 0.f; t[k] = 0.f; }
@@ -316,35 +367,49 @@ __global__ __launch_bounds__(256) void k_inact_bwd_reduce(const T* __restrict__ 
         const size_t img = (size_t)n * Hp * Wp;
         const T* rbase = raw + img * ldc_raw + coff_raw + c0;
         T* Gbase = G + img * ldc_G + coff_G + c0;
-        int q = q0 + m.px;
-        int y = q / W, x = q - y * W;
-        constexpr int U = FNET_EW_UR;   // pixels per trip: gradient and activation loads of both pixels are issued before the arithmetic
-        for (; q < q1; q += U * m.ppi) {
-            float acc[U][8];
-            Vec8<T> r[U];
-            size_t pix[U];
-            bool ok[U];
+        const T* g1img = g1 + img * ldc_g1 + coff_g1 + c0;
+        const T* g2img = g2 ? g2 + img * ldc_g2 + coff_g2 + c0 : nullptr;
+        const bool f1 = fold1 && pm != FNET_PAD_ZEROS, f2 = fold2 && pm != FNET_PAD_ZEROS;
+        const int fylo = pad_lo(H, pm), fyhi = pad_hi(H, pm), fxlo = pad_lo(W, pm), fxhi = pad_hi(W, pm);
+        PixWalk w(q, qs, W);
+        auto trip = [&](auto uc, auto gc) {
+            constexpr int UU = decltype(uc)::value;
+            constexpr bool G2 = decltype(gc)::value != 0;
+            Vec8<T> a1[UU], a2[UU], r[UU];
+            size_t pix[UU];
+            int yy[UU], xx[UU];
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                ok[u] = q + u * m.ppi < q1;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) acc[u][k] = 0.f;
-                if (ok[u]) {
-                    fold_read8<T>(g1 + coff_g1 + c0, n, y, x, H, W, ldc_g1, pm, fold1, acc[u]);
-                    if (g2) fold_read8<T>(g2 + coff_g2 + c0, n, y, x, H, W, ldc_g2, pm, fold2, acc[u]);
-                    pix[u] = (size_t)(y + 1) * Wp + x + 1;
-                    r[u].load(rbase + pix[u] * ldc_raw);
-                }
-                x += m.ppi;
-                while (x >= W) { x -= W; ++y; }
+            for (int u = 0; u < UU; ++u) {
+                yy[u] = w.y; xx[u] = w.x;
+                pix[u] = (size_t)(w.y + 1) * Wp + w.x + 1;
+                a1[u].load(g1img + pix[u] * ldc_g1);
+                if (G2) a2[u].load(g2img + pix[u] * ldc_g2);
+                r[u].load(rbase + pix[u] * ldc_raw);
+                w.step();
             }
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                if (!ok[u]) continue;
+            for (int u = 0; u < UU; ++u) {
+                float acc[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc[k] = G2 ? a1[u].v[k] + a2[u].v[k] : a1[u].v[k];
+                if ((f1 || f2) && (yy[u] == fylo || yy[u] == fyhi || xx[u] == fxlo || xx[u] == fxhi)) {
+                    // a pixel the ring copies (row/column 0 and n-1 for replicate and circular, 1 and n-2 for reflect): add the
+                    // ring positions that are copies of it (same order as fold_read8: g1's, then g2's)
+                    if (G2) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) acc[k] = a1[u].v[k];
+                    }
+                    if (f1) fold_extras8<T>(g1img, yy[u], xx[u], H, W, ldc_g1, pm, acc);
+                    if (G2) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) acc[k] += a2[u].v[k];
+                        if (f2) fold_extras8<T>(g2img, yy[u], xx[u], H, W, ldc_g2, pm, acc);
+                    }
+                }
                 Vec8<T> go;
 #pragma unroll
-                for (int k = 0; k < 8; ++k) go.v[k] = acc[u][k];
-                go.store(Gbase + pix[u] * ldc_G);
+                for (int k = 0; k < 8; ++k) go.v[k] = acc[k];
+                go.store_nt(Gbase + pix[u] * ldc_G);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     // use the value as stored (bf16-rounded in bf16 mode) so that pass 2 sees the same G
@@ -357,6 +422,14 @@ __global__ __launch_bounds__(256) void k_inact_bwd_reduce(const T* __restrict__ 
                     t[k] = fmaf(dz, xh, t[k]);
                 }
             }
+        };
+        constexpr int U = FNET_EW_UR;   // pixels per trip: the gradient and activation loads of all of them are issued first
+        if (g2img) {
+            for (; q + (U - 1) * qs < q1; q += U * qs) trip(IntC<U>{}, IntC<1>{});
+            for (; q < q1; q += qs) trip(IntC<1>{}, IntC<1>{});
+        } else {
+            for (; q + (U - 1) * qs < q1; q += U * qs) trip(IntC<U>{}, IntC<0>{});
+            for (; q < q1; q += qs) trip(IntC<1>{}, IntC<0>{});
         }
     }
 #pragma unroll
@@ -384,7 +457,8 @@ __global__ __launch_bounds__(256) void k_inact_bwd_apply(const T* __restrict__ G
     const CgMap m(C);
     if (!m.active) return;
     const int n = blockIdx.y, Hp = H + 2, Wp = W + 2, c0 = m.cg * 8;
-    const int p0 = blockIdx.x * p_per_block, p1 = min(Hp * Wp, p0 + p_per_block);
+    int p, ps, p1;
+    m.range(Hp * Wp, p_per_block, p, ps, p1);
     const float inv = 1.f / (float)(H * W);
     float xa[8], xb[8], gam[8], bet[8], dsc[8], k0[8], k1[8], k2[8];
 #pragma unroll
@@ -402,45 +476,35 @@ __global__ __launch_bounds__(256) void k_inact_bwd_apply(const T* __restrict__ G
     const T* Gbase = G + img * ldc_G + coff_G + c0;
     const T* rbase = raw + img * ldc_raw + coff_raw + c0;
     T* dbase = draw + img * ldc_d + coff_d + c0;
-    int p = p0 + m.px;
-    int y = p / Wp, x = p - y * Wp;
-    constexpr int U = FNET_EW_U;       // pixels per trip: all loads first (see k_in_stats_part)
-    for (; p < p1; p += U * m.ppi) {
-        Vec8<T> g[U], r[U];
-        int st[U];             // 0 = past the end, 1 = ring pixel (zero), 2 = interior
+    PixWalk w(p, ps, Wp);
+    auto trip = [&](auto uc) {
+        constexpr int UU = decltype(uc)::value;
+        Vec8<T> g[UU], r[UU];
+        uint32_t keep[UU];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            st[u] = 0;
-            const int pu = p + u * m.ppi;
-            if (pu < p1) {
-                st[u] = (y == 0 || y == Hp - 1 || x == 0 || x == Wp - 1) ? 1 : 2;
-                if (st[u] == 2) {
-                    g[u].load(Gbase + (size_t)pu * ldc_G);
-                    r[u].load(rbase + (size_t)pu * ldc_raw);
-                }
-            }
-            x += m.ppi;
-            while (x >= Wp) { x -= Wp; ++y; }
+        for (int u = 0; u < UU; ++u) {
+            keep[u] = (w.y == 0 || w.y == Hp - 1 || w.x == 0 || w.x == Wp - 1) ? 0u : 0xffffffffu;   // ring: loaded all the same (valid memory), zeroed below
+            const size_t pu = (size_t)(p + u * ps);
+            g[u].load(Gbase + pu * ldc_G);
+            r[u].load(rbase + pu * ldc_raw);
+            w.step();
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (st[u] == 0) continue;
+        for (int u = 0; u < UU; ++u) {
             Vec8<T> o;
-            if (st[u] == 1) {
 #pragma unroll
-                for (int k = 0; k < 8; ++k) o.v[k] = 0.f;
-            } else {
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const float xh = fmaf(r[u].v[k], xa[k], xb[k]);
-                    const float uu = fmaf(xh, gam[k], bet[k]);
-                    const float dz = g[u].v[k] * dsc[k] * act_bwd_t<ACT>(uu);
-                    o.v[k] = k0[k] * (dz - k1[k] - xh * k2[k]);
-                }
+            for (int k = 0; k < 8; ++k) {
+                const float xh = fmaf(r[u].v[k], xa[k], xb[k]);
+                const float uu = fmaf(xh, gam[k], bet[k]);
+                const float dz = g[u].v[k] * dsc[k] * act_bwd_t<ACT>(uu);
+                o.v[k] = keep_bits(k0[k] * (dz - k1[k] - xh * k2[k]), keep[u]);
             }
-            o.store(dbase + (size_t)(p + u * m.ppi) * ldc_d);
+            o.store_nt(dbase + (size_t)(p + u * ps) * ldc_d);
         }
-    }
+    };
+    constexpr int U = FNET_EW_U;       // pixels per trip, all loads first
+    for (; p + (U - 1) * ps < p1; p += U * ps) trip(IntC<U>{});
+    for (; p < p1; p += ps) trip(IntC<1>{});
 }
 
 // ------------------------------------------------------------------ AFFINE_GRAD: dgamma += sum_n S2, dbeta += sum_n S1
@@ -691,10 +755,15 @@ inline bool vec_ok(const void* p, int ldc, int coff, int C, int dtype) {
            (((uintptr_t)p) % (8 * esz)) == 0;
 }
 inline bool vec_ok_opt(const void* p, int ldc, int coff, int C, int dtype) { return p == nullptr || vec_ok(p, ldc, coff, C, dtype); }
-// cg kernels: pixels per block so that the launch has ~2048 blocks (8 per CU) but every thread still walks >= 4 pixels
-inline int cg_pixels_per_block(int npix, int B, int C, int* chunks_out) {
+// cg kernels: pixels per block so that the launch has about `target` blocks but every thread still walks >= 4 pixels.
+// Measured on MI355X (tools/ew_bench.py, B = 64): 768-1024 blocks (3-4 per CU) beat 2048 by 8-10 % on the 128^2 and 64^2
+// layers -- every block pays a prologue of ~30 dependent scalar loads plus the dropout hash before its first pixel -- and
+// 256-512 lose again to the tail.  FNET_CG_BLOCKS overrides the target (tuning knob).
+inline int cg_pixels_per_block(int npix, int B, int C, int* chunks_out, int target) {
     const int ppi = kThreads / (C >> 3);
-    int chunks = (2048 + B - 1) / B;
+    static const int forced = [] { const char* e = getenv("FNET_CG_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 0; }();
+    if (forced) target = forced;
+    int chunks = (target + B - 1) / B;
     const int max_chunks = (npix + ppi * 4 - 1) / (ppi * 4);
     if (chunks > max_chunks) chunks = max_chunks;
     if (chunks < 1) chunks = 1;
@@ -741,7 +810,7 @@ int fnet_op_in_stats(const FnetOp& op, hipStream_t st) {
         // one coalesced pass into per-block partials + ordered finalize (bf16 plans; p[2] = scratch of i[6] floats);
         // fp32 plans, or no scratch, keep the exact two-pass kernel below
         int chunks;
-        const int per = cg_pixels_per_block(H * W, B, C, &chunks);
+        const int per = cg_pixels_per_block(H * W, B, C, &chunks, 1024);
         FNET_CHECK_ARG((long long)B * chunks * C * 2 <= (long long)op.i[6]);
         hipLaunchKernelGGL(k_in_stats_part<bf16_t>, dim3(chunks, B), dim3(kThreads), 0, st, (const bf16_t*)op.p[0], (float*)op.p[2], H, W, C,
                            op.i[4], op.i[5], per);
@@ -768,7 +837,7 @@ int fnet_op_apply(const FnetOp& op, hipStream_t st) {
     FNET_CHECK_ARG(op.p[1] == 0 || (op.p[2] != 0 && op.p[3] != 0));
     FNET_CHECK_ARG(op.f[0] >= 0.f && op.f[0] < 1.f && cg_ok(C, B));
     int chunks;
-    const int per = cg_pixels_per_block((H + 2) * (W + 2), B, C, &chunks);
+    const int per = cg_pixels_per_block((H + 2) * (W + 2), B, C, &chunks, 1024);
     DISPATCH_ACT(op.i[10], DISPATCH_T(op.dtype, hipLaunchKernelGGL((k_apply<T, ACT>), dim3(chunks, B), dim3(kThreads), 0, st,
                                             (const T*)op.p[0], (const float2*)op.p[1], (const float*)op.p[2],
                                             (const float*)op.p[3], (const T*)op.p[4], (T*)op.p[5], H, W, C, op.i[4],
@@ -791,7 +860,7 @@ int fnet_op_inact_bwd_reduce(const FnetOp& op, hipStream_t st) {
     FNET_CHECK_ARG(vec_ok((void*)op.p[6], op.i[10], op.i[11], C, op.dtype));
     FNET_CHECK_ARG(op.p[3] && op.p[4] && op.p[5] && op.p[7] && cg_ok(C, B) && ((op.p[8] == 0) == (op.p[9] == 0)));
     int chunks;
-    const int per = cg_pixels_per_block(H * W, B, C, &chunks);
+    const int per = cg_pixels_per_block(H * W, B, C, &chunks, 768);
     DISPATCH_ACT(op.i[14], DISPATCH_T(op.dtype,
                hipLaunchKernelGGL((k_inact_bwd_reduce<T, ACT>), dim3(chunks, B), dim3(kThreads), 0, st, (const T*)op.p[0],
                                   (const T*)op.p[1], (const T*)op.p[2], (const float2*)op.p[3], (const float*)op.p[4],
@@ -812,7 +881,7 @@ int fnet_op_inact_bwd_apply(const FnetOp& op, hipStream_t st) {
     FNET_CHECK_ARG(vec_ok((void*)op.p[6], op.i[8], op.i[9], C, op.dtype));
     FNET_CHECK_ARG(op.p[2] && op.p[3] && op.p[4] && op.p[5] && cg_ok(C, B));
     int chunks;
-    const int per = cg_pixels_per_block((H + 2) * (W + 2), B, C, &chunks);
+    const int per = cg_pixels_per_block((H + 2) * (W + 2), B, C, &chunks, 1024);
     DISPATCH_ACT(op.i[10], DISPATCH_T(op.dtype, hipLaunchKernelGGL((k_inact_bwd_apply<T, ACT>), dim3(chunks, B), dim3(kThreads), 0,
                                             st, (const T*)op.p[0], (const T*)op.p[1], (const float2*)op.p[2],
                                             (const float*)op.p[3], (const float*)op.p[4], (const float2*)op.p[5],

@@ -758,7 +758,9 @@ inline bool vec_ok_opt(const void* p, int ldc, int coff, int C, int dtype) { ret
 // cg kernels: pixels per block so that the launch has about `target` blocks but every thread still walks >= 4 pixels.
 // Measured on MI355X (tools/ew_bench.py, B = 64): 768-1024 blocks (3-4 per CU) beat 2048 by 8-10 % on the 128^2 and 64^2
 // layers -- every block pays a prologue of ~30 dependent scalar loads plus the dropout hash before its first pixel -- and
-// 256-512 lose again to the tail.  FNET_CG_BLOCKS overrides the target (tuning knob).
+// 256-512 lose again to the tail; 1024 blocks of a power-of-two image (16 equal power-of-two ranges) was the one bad point
+// above 512 in the backward reduce: every block then streams at the same address modulo a large power of two.
+// FNET_CG_BLOCKS overrides the target (tuning knob).
 inline int cg_pixels_per_block(int npix, int B, int C, int* chunks_out, int target) {
     const int ppi = kThreads / (C >> 3);
     static const int forced = [] { const char* e = getenv("FNET_CG_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 0; }();
@@ -810,7 +812,7 @@ int fnet_op_in_stats(const FnetOp& op, hipStream_t st) {
         // one coalesced pass into per-block partials + ordered finalize (bf16 plans; p[2] = scratch of i[6] floats);
         // fp32 plans, or no scratch, keep the exact two-pass kernel below
         int chunks;
-        const int per = cg_pixels_per_block(H * W, B, C, &chunks, 1024);
+        const int per = cg_pixels_per_block(H * W, B, C, &chunks, 768);
         FNET_CHECK_ARG((long long)B * chunks * C * 2 <= (long long)op.i[6]);
         hipLaunchKernelGGL(k_in_stats_part<bf16_t>, dim3(chunks, B), dim3(kThreads), 0, st, (const bf16_t*)op.p[0], (float*)op.p[2], H, W, C,
                            op.i[4], op.i[5], per);
@@ -837,7 +839,7 @@ int fnet_op_apply(const FnetOp& op, hipStream_t st) {
     FNET_CHECK_ARG(op.p[1] == 0 || (op.p[2] != 0 && op.p[3] != 0));
     FNET_CHECK_ARG(op.f[0] >= 0.f && op.f[0] < 1.f && cg_ok(C, B));
     int chunks;
-    const int per = cg_pixels_per_block((H + 2) * (W + 2), B, C, &chunks, 1024);
+    const int per = cg_pixels_per_block((H + 2) * (W + 2), B, C, &chunks, 768);
     DISPATCH_ACT(op.i[10], DISPATCH_T(op.dtype, hipLaunchKernelGGL((k_apply<T, ACT>), dim3(chunks, B), dim3(kThreads), 0, st,
                                             (const T*)op.p[0], (const float2*)op.p[1], (const float*)op.p[2],
                                             (const float*)op.p[3], (const T*)op.p[4], (T*)op.p[5], H, W, C, op.i[4],
@@ -881,7 +883,7 @@ int fnet_op_inact_bwd_apply(const FnetOp& op, hipStream_t st) {
     FNET_CHECK_ARG(vec_ok((void*)op.p[6], op.i[8], op.i[9], C, op.dtype));
     FNET_CHECK_ARG(op.p[2] && op.p[3] && op.p[4] && op.p[5] && cg_ok(C, B));
     int chunks;
-    const int per = cg_pixels_per_block((H + 2) * (W + 2), B, C, &chunks, 1024);
+    const int per = cg_pixels_per_block((H + 2) * (W + 2), B, C, &chunks, 768);
     DISPATCH_ACT(op.i[10], DISPATCH_T(op.dtype, hipLaunchKernelGGL((k_inact_bwd_apply<T, ACT>), dim3(chunks, B), dim3(kThreads), 0,
                                             st, (const T*)op.p[0], (const T*)op.p[1], (const float2*)op.p[2],
                                             (const float*)op.p[3], (const float*)op.p[4], (const float2*)op.p[5],

@@ -57,6 +57,9 @@ typedef const __attribute__((address_space(1))) void gbl_void_t;
 #ifndef FNET_CONV_ABLATE
 #define FNET_CONV_ABLATE 0
 #endif
+#ifndef FNET_CONV_STAMPS
+#define FNET_CONV_STAMPS 0
+#endif
 
 struct ConvTile {          // wave-uniform description of one (pixel tile, cout tile) work item
     long long f0;
@@ -65,13 +68,24 @@ struct ConvTile {          // wave-uniform description of one (pixel tile, cout 
     __amdgpu_buffer_rsrc_t rs;
 };
 
-template <int TN>
-__global__ __launch_bounds__(256, 2) void k_conv3x3_dma(const bf16_t* __restrict__ src, const bf16_t* __restrict__ Wk,
+// Two block shapes: NW = 4 waves (256 pixels per tile, two blocks per CU) and NW = 8 waves (512 pixels per tile, one block
+// per CU, TN up to 128).  The kernel is bound by the LDS-DMA issue rate (every 1-KB piece costs its wave 60-185 cycles,
+// MI355X_MICROARCH.md), i.e. by bytes staged per FLOP: per 16-channel stage a tile stages 9*TN weight rows + (TM + 2Wp + 2)
+// pixels for TM*TN*9 MACs, so the 512 x 128 tile stages 2.3x fewer bytes per FLOP than the 256 x 64 one; the small tile
+// remains for layers with too few tiles to fill 256 big-tile blocks.
+template <int TN, int NW>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_conv3x3_dma(const bf16_t* __restrict__ src, const bf16_t* __restrict__ Wk,
                                                         const float* __restrict__ bias, bf16_t* __restrict__ dst, int Npix, int Wp,
                                                         int Cin, int ldc_in, int coff_in, int Cout, int ldc_out, int coff_out,
                                                         int n_mtiles, int n_ntiles, int rinp, int bufsz, float* __restrict__ stats_part,
                                                         int H, int W) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+#if FNET_CONV_STAMPS
+    float* stamps = stats_part;
+    stats_part = nullptr;
+#endif
+    constexpr int TMB = NW * 64;                    // pixels per tile
+    constexpr int NTHR = NW * 64;
     constexpr int NT = TN / 32;
     constexpr int WB = 9 * TN * 32;                 // weight image bytes
     constexpr int NPW = 9 * TN / 32;                // weight DMA pieces per stage
@@ -97,7 +111,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_dma(const bf16_t* __restrict
         const int xcd = L & 7, j = L >> 3;
         const int mt = xcd * cpx + j / n_ntiles;
         if (mt >= n_mtiles) return false;
-        T.f0 = (long long)mt * TM;
+        T.f0 = (long long)mt * TMB;
         T.n0 = (j - (j / n_ntiles) * n_ntiles) * TN;
         const long long gbase = T.f0 - Wp - 1;
         const long long wpix = gbase > 0 ? gbase : 0;
@@ -108,23 +122,26 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_dma(const bf16_t* __restrict
         T.in_lane_off = (int)(((long long)(lane >> 1) + (gbase - wpix)) * ldc_in + coff_in + dh * 8) * 2;
         return true;
     };
-    auto issue = [&](const ConvTile& T, int s, int buf) {
+    // one DMA piece (1 KB = 32 rows x 32 B) of stage s of tile T into stage buffer `buf`: pieces [0, npi) are the input run,
+    // [npi, npi + NPW) the weight slab
+    auto issue_piece = [&](const ConvTile& T, int s, int buf, int q) {
         unsigned char* wdst = smem + buf * bufsz;
-        unsigned char* idst = wdst + WB;
-        for (int q = wave; q < npi + NPW; q += 4) {
-            if (q < npi) {
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(T.rs, (lds_void_t*)(idst + q * 1024), 16,
-                                                         T.in_lane_off + q * in_piece_stride + s * (KC * 2), 0, 0, 0);
-            } else {
-                const int qw = q - npi;
-                const int row = qw * 32 + wrow;
-                const int t = row / TN;
-                int co = T.n0 + (row - t * TN);
-                co = co < Cout ? co : Cout - 1;
-                const int woff = (int)(((((size_t)s * 9 + t) * Cout + co) * 16 + dh * 8) * 2);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_void_t*)(wdst + qw * 1024), 16, woff, 0, 0, 0);
-            }
+        if (q < npi) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(T.rs, (lds_void_t*)(wdst + WB + q * 1024), 16,
+                                                     T.in_lane_off + q * in_piece_stride + s * (KC * 2), 0, 0, 0);
+        } else {
+            const int qw = q - npi;
+            const int row = qw * 32 + wrow;
+            const int t = row / TN;
+            int co = T.n0 + (row - t * TN);
+            co = co < Cout ? co : Cout - 1;
+            const int woff = (int)(((((size_t)s * 9 + t) * Cout + co) * 16 + dh * 8) * 2);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_void_t*)(wdst + qw * 1024), 16, woff, 0, 0, 0);
         }
+    };
+    const int npieces = npi + NPW;
+    auto issue = [&](const ConvTile& T, int s, int buf) {
+        for (int q = wave; q < npieces; q += NW) issue_piece(T, s, buf, q);
     };
 
     // fragment read addresses (bytes, relative to a stage buffer): 9 taps x 2 pixel sub-tiles; weights: lane base + immediates
@@ -151,22 +168,37 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_dma(const bf16_t* __restrict
     if (!have) return;
     int L = blockIdx.x;
     unsigned g = 0;                       // running stage counter: stage buffer = g & 1
+#if FNET_CONV_STAMPS
+    // diagnostic build (tools/conv_bench.py): wave 0 of every block adds its cycles spent waiting at the stage barrier, in the
+    // tap loops, in the epilogue and in total to the first 5 int64 of the statistics scratch (no statistics in this build)
+    long long st_bar = 0, st_loop = 0, st_epi = 0, st_t0 = __builtin_amdgcn_s_memtime(), st_a, st_b;
+#define STAMP(x) x = __builtin_amdgcn_s_memtime()
+#else
+#define STAMP(x)
+#endif
     issue(cur, 0, 0);
     while (true) {
         bool have_next = false;
         for (int s = 0; s < nst; ++s, ++g) {
+            STAMP(st_a);
             __syncthreads();  // this stage has landed (vmcnt(0) + barrier); every wave is done with the other buffer
-#if FNET_CONV_ABLATE != 2
-            if (s + 1 < nst) {
-                issue(cur, s + 1, (g + 1) & 1);
-            } else {
-                // last stage of this tile: start the next tile's first stage now (it lands during the epilogue)
-                L += gridDim.x;
-                have_next = tile_of(L, nxt);
-                if (have_next) issue(nxt, 0, (g + 1) & 1);
-            }
+            STAMP(st_b);
+#if FNET_CONV_STAMPS
+            st_bar += st_b - st_a;
+#endif
+            // The next stage's DMA (of this tile, or stage 0 of the block's next tile: it then lands during the epilogue) is
+            // issued one piece per tap INSIDE the tap loop below: a piece costs the issuing wave 60-185 cycles, which hide behind
+            // the four MFMAs of a tap instead of delaying every wave's first MFMA after the barrier.
+            const bool last = s + 1 == nst;
+            if (last) { L += gridDim.x; have_next = tile_of(L, nxt); }
+            ConvTile Ti = cur;             // by value (a reference to one of two structs would put both in scratch)
+            if (last) Ti = nxt;
+            const int si = last ? 0 : s + 1;
+            const int nbuf = (g + 1) & 1;
+#if FNET_CONV_ABLATE == 2
+            const int qlim = 0;
 #else
-            if (s + 1 == nst) { L += gridDim.x; have_next = tile_of(L, nxt); }
+            const int qlim = (!last || have_next) ? npieces : 0;
 #endif
             const unsigned bb = (g & 1) ? (unsigned)bufsz : 0u;
             // fragment reads run one tap ahead of the MFMAs (two register sets, static indexing after unrolling)
@@ -185,6 +217,10 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_dma(const bf16_t* __restrict
                     for (int ns = 0; ns < NT; ++ns)
                         wa[n][ns] = *reinterpret_cast<const bf16x8*>(smem + waddr + bb + ((t + 1) * TN + ns * 32) * 32);
                 }
+                {
+                    const int q = wave + NW * t;
+                    if (q < qlim) issue_piece(Ti, si, nbuf, q);
+                }
                 __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of this tap's MFMAs (hipcc otherwise re-serialises them)
 #pragma unroll
                 for (int ms = 0; ms < 2; ++ms)
@@ -196,132 +232,161 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_dma(const bf16_t* __restrict
                         acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[c][ns], xb[c][ms], acc[ms][ns], 0, 0, 0);
 #endif
             }
+            for (int q = wave + NW * 9; q < qlim; q += NW) issue_piece(Ti, si, nbuf, q);   // wide images: more than 9 pieces per wave
+#if FNET_CONV_STAMPS
+            STAMP(st_a);
+            st_loop += st_a - st_b;
+#endif
         }
+        STAMP(st_a);
         __syncthreads();  // all fragment reads of the last stage done: its buffer now holds the output tile
 
-        // D[row = cout][col = pixel]: lane (r, h) holds pixel r, couts (i&3) + 8*(i>>2) + 4*h.  Output tile [256 px][TN] bf16,
-        // pitch TN*2, 16-B chunk index XOR-swizzled with the pixel index.
+        // D[row = cout][col = pixel]: lane (r, h) holds pixel r, couts (i&3) + 8*(i>>2) + 4*h.  The output goes through LDS in
+        // slices of TNE <= 64 couts: slice tile [TMB px][TNE] bf16, pitch TNE*2, 16-B chunk index XOR-swizzled with the pixel
+        // index, then streams out 16 B per lane.
         unsigned char* ot = smem + ((g - 1) & 1) * bufsz;
-        constexpr int PO = TN * 2;
-        constexpr int CH = TN / 8;             // 16-B chunks per pixel
+        constexpr int TNE = TN > 64 ? 64 : TN; // couts per output slice
+        constexpr int NTE = TNE / 32;
+        constexpr int PO = TNE * 2;
+        constexpr int CH = TNE / 8;            // 16-B chunks per pixel
+        constexpr int PPI = NTHR / CH;         // pixels per pass
         const long long f0 = cur.f0;
-        const int n0 = cur.n0;
-#pragma unroll
-        for (int ns = 0; ns < NT; ++ns)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int col = ns * 32 + 8 * q + 4 * h;
-                float bv[4] = {0.f, 0.f, 0.f, 0.f};
-                if (bias) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) bv[k] = (n0 + col + k < Cout) ? bias[n0 + col + k] : 0.f;
-                }
-#pragma unroll
-                for (int ms = 0; ms < 2; ++ms) {
-                    const int px = wave * 64 + ms * 32 + r;
-                    uint2 v;
-                    v.x = f2bf_pk(acc[ms][ns][4 * q + 0] + bv[0], acc[ms][ns][4 * q + 1] + bv[1]);
-                    v.y = f2bf_pk(acc[ms][ns][4 * q + 2] + bv[2], acc[ms][ns][4 * q + 3] + bv[3]);
-                    *reinterpret_cast<uint2*>(ot + px * PO + ((((col >> 3) ^ px) & (CH - 1)) << 4) + (col & 4) * 2) = v;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) acc[ms][ns][4 * q + k] = 0.f;
-                }
-            }
-        __syncthreads();
-        constexpr int PPI = kThreads / CH;     // pixels per pass
         const int chunk = tid % CH, px0 = tid / CH;
-        const bool cvalid = n0 + chunk * 8 < Cout;
-        if (!stats_part) {
-            if (cvalid) {
 #pragma unroll
-                for (int k = 0; k < TM / PPI; ++k) {
-                    const int px = px0 + k * PPI;
-                    const long long f = f0 + px;
-                    if (f < Npix) {
-                        const uint4 v = *reinterpret_cast<const uint4*>(ot + px * PO + (((chunk ^ px) & (CH - 1)) << 4));
-                        st_stream16(dst + (size_t)f * ldc_out + coff_out + n0 + chunk * 8, v);
+        for (int sl = 0; sl < TN / TNE; ++sl) {
+            const int n0 = cur.n0 + sl * TNE;
+            if (sl > 0) __syncthreads();       // the previous slice has been read out of the tile
+#pragma unroll
+            for (int nl = 0; nl < NTE; ++nl) {
+                const int ns = sl * NTE + nl;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int col = nl * 32 + 8 * q + 4 * h;
+                    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (bias) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) bv[k] = (n0 + col + k < Cout) ? bias[n0 + col + k] : 0.f;
+                    }
+#pragma unroll
+                    for (int ms = 0; ms < 2; ++ms) {
+                        const int px = wave * 64 + ms * 32 + r;
+                        uint2 v;
+                        v.x = f2bf_pk(acc[ms][ns][4 * q + 0] + bv[0], acc[ms][ns][4 * q + 1] + bv[1]);
+                        v.y = f2bf_pk(acc[ms][ns][4 * q + 2] + bv[2], acc[ms][ns][4 * q + 3] + bv[3]);
+                        *reinterpret_cast<uint2*>(ot + px * PO + ((((col >> 3) ^ px) & (CH - 1)) << 4) + (col & 4) * 2) = v;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) acc[ms][ns][4 * q + k] = 0.f;
                     }
                 }
             }
-        } else {
-            // Fused InstanceNorm statistics (ml/models/unet.py:22-23): while the tile streams out, every thread (fixed
-            // 8-channel chunk) sums x and x^2 of the bf16 values it stores, over interior pixels only, separately for the (at
-            // most two) images the tile touches (host guarantees (H+2)(W+2) >= 256).  Lanes that own the same chunk are
-            // combined with wave shuffles, the four waves through 2 KB of LDS, and the block partial goes to
-            // stats_part[tile][slot 0/1][Cout][2] with plain stores; IN_STATS (tile mode) adds them in tile order.
-            const int Hp = H + 2, HpWp = Hp * Wp;
-            const int n_first = (int)(f0 / HpWp);
-            const long long f_last = (f0 + TM - 1 < Npix ? f0 + TM - 1 : (long long)Npix - 1);
-            const int nslots = ((int)(f_last / HpWp) != n_first) ? 2 : 1;
-            float sa[2][8], qa[2][8];
+            __syncthreads();
+            const bool cvalid = n0 + chunk * 8 < Cout;
+            if (NW != 4 || TN > 64 || !stats_part) {
+                if (cvalid) {
 #pragma unroll
-            for (int sl = 0; sl < 2; ++sl)
-#pragma unroll
-                for (int k = 0; k < 8; ++k) { sa[sl][k] = 0.f; qa[sl][k] = 0.f; }
-            const int fi = (int)f0 + px0;
-            int n = fi / HpWp;
-            const int rem = fi - n * HpWp;
-            int y = rem / Wp, x = rem - y * Wp;
-#pragma unroll
-            for (int k = 0; k < TM / PPI; ++k) {
-                const int px = px0 + k * PPI;
-                const long long f = f0 + px;
-                if (f < Npix && cvalid) {
-                    const uint4 v = *reinterpret_cast<const uint4*>(ot + px * PO + (((chunk ^ px) & (CH - 1)) << 4));
-                    st_stream16(dst + (size_t)f * ldc_out + coff_out + n0 + chunk * 8, v);
-                    if (y >= 1 && y <= H && x >= 1 && x <= W) {
-                        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-                        const bool second = n != n_first;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float lo = __uint_as_float(w[e] << 16), hi = __uint_as_float(w[e] & 0xffff0000u);
-                            if (second) {
-                                sa[1][2 * e] += lo; qa[1][2 * e] = fmaf(lo, lo, qa[1][2 * e]);
-                                sa[1][2 * e + 1] += hi; qa[1][2 * e + 1] = fmaf(hi, hi, qa[1][2 * e + 1]);
-                            } else {
-                                sa[0][2 * e] += lo; qa[0][2 * e] = fmaf(lo, lo, qa[0][2 * e]);
-                                sa[0][2 * e + 1] += hi; qa[0][2 * e + 1] = fmaf(hi, hi, qa[0][2 * e + 1]);
-                            }
+                    for (int k = 0; k < TMB / PPI; ++k) {
+                        const int px = px0 + k * PPI;
+                        const long long f = f0 + px;
+                        if (f < Npix) {
+                            const uint4 v = *reinterpret_cast<const uint4*>(ot + px * PO + (((chunk ^ px) & (CH - 1)) << 4));
+                            st_stream16(dst + (size_t)f * ldc_out + coff_out + n0 + chunk * 8, v);
                         }
                     }
                 }
-                x += PPI;
-                while (x >= Wp) { x -= Wp; ++y; }
-                if (y >= Hp) { y -= Hp; ++n; }
-            }
-            // lanes l and l + CH, l + 2CH, ... own the same chunk: butterfly over those lane bits, then lanes 0..CH-1 hold
-            // the wave's sums
-            float* red = reinterpret_cast<float*>(ot + TM * PO);     // [4 waves][CH][16] floats
-            const int mtile = (int)(f0 / TM);
-            float* out = stats_part + ((size_t)mtile * 2) * Cout * 2;
-            for (int sl = 0; sl < 2; ++sl) {
-                float v16[16];
-                if (sl < nslots) {
+            } else {
+                // Fused InstanceNorm statistics (ml/models/unet.py:22-23), small-tile kernel only: while the tile streams out,
+                // every thread (fixed 8-channel chunk) sums x and x^2 of the bf16 values it stores, over interior pixels only,
+                // separately for the (at most two) images the tile touches (host guarantees (H+2)(W+2) >= 256).  Lanes that own
+                // the same chunk are combined with wave shuffles, the four waves through 2 KB of LDS, and the block partial
+                // goes to stats_part[tile][slot 0/1][Cout][2] with plain stores; IN_STATS (tile mode) adds them in tile order.
+                const int Hp = H + 2, HpWp = Hp * Wp;
+                const int n_first = (int)(f0 / HpWp);
+                const long long f_last = (f0 + TMB - 1 < Npix ? f0 + TMB - 1 : (long long)Npix - 1);
+                const int nslots = ((int)(f_last / HpWp) != n_first) ? 2 : 1;
+                float sa[2][8], qa[2][8];
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) { v16[k] = sl ? sa[1][k] : sa[0][k]; v16[8 + k] = sl ? qa[1][k] : qa[0][k]; }
+                for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-                    for (int off = CH; off < 64; off <<= 1)
+                    for (int k = 0; k < 8; ++k) { sa[s2][k] = 0.f; qa[s2][k] = 0.f; }
+                const int fi = (int)f0 + px0;
+                int n = fi / HpWp;
+                const int rem = fi - n * HpWp;
+                int y = rem / Wp, x = rem - y * Wp;
 #pragma unroll
-                        for (int k = 0; k < 16; ++k) v16[k] += __shfl_xor(v16[k], off, 64);
-                    if (lane < CH) {
+                for (int k = 0; k < TMB / PPI; ++k) {
+                    const int px = px0 + k * PPI;
+                    const long long f = f0 + px;
+                    if (f < Npix && cvalid) {
+                        const uint4 v = *reinterpret_cast<const uint4*>(ot + px * PO + (((chunk ^ px) & (CH - 1)) << 4));
+                        st_stream16(dst + (size_t)f * ldc_out + coff_out + n0 + chunk * 8, v);
+                        if (y >= 1 && y <= H && x >= 1 && x <= W) {
+                            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+                            const bool second = n != n_first;
 #pragma unroll
-                        for (int k = 0; k < 16; ++k) red[(wave * CH + lane) * 16 + k] = v16[k];
+                            for (int e = 0; e < 4; ++e) {
+                                const float lo = __uint_as_float(w[e] << 16), hi = __uint_as_float(w[e] & 0xffff0000u);
+                                if (second) {
+                                    sa[1][2 * e] += lo; qa[1][2 * e] = fmaf(lo, lo, qa[1][2 * e]);
+                                    sa[1][2 * e + 1] += hi; qa[1][2 * e + 1] = fmaf(hi, hi, qa[1][2 * e + 1]);
+                                } else {
+                                    sa[0][2 * e] += lo; qa[0][2 * e] = fmaf(lo, lo, qa[0][2 * e]);
+                                    sa[0][2 * e + 1] += hi; qa[0][2 * e + 1] = fmaf(hi, hi, qa[0][2 * e + 1]);
+                                }
+                            }
+                        }
                     }
+                    x += PPI;
+                    while (x >= Wp) { x -= Wp; ++y; }
+                    if (y >= Hp) { y -= Hp; ++n; }
                 }
-                __syncthreads();
-                if (tid < CH * 16) {
-                    float a = 0.f;
-                    if (sl < nslots) a = (red[tid] + red[CH * 16 + tid]) + (red[2 * CH * 16 + tid] + red[3 * CH * 16 + tid]);
-                    const int cg = tid >> 4, k = tid & 15;
-                    const int c = n0 + cg * 8 + (k & 7);
-                    if (c < Cout) out[((size_t)sl * Cout + c) * 2 + (k >> 3)] = a;
+                // lanes l and l + CH, l + 2CH, ... own the same chunk: butterfly over those lane bits, then lanes 0..CH-1
+                // hold the wave's sums
+                float* red = reinterpret_cast<float*>(ot + TMB * PO);     // [4 waves][CH][16] floats
+                const int mtile = (int)(f0 / TMB);
+                float* out = stats_part + ((size_t)mtile * 2) * Cout * 2;
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    float v16[16];
+                    if (s2 < nslots) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) { v16[k] = s2 ? sa[1][k] : sa[0][k]; v16[8 + k] = s2 ? qa[1][k] : qa[0][k]; }
+#pragma unroll
+                        for (int off = CH; off < 64; off <<= 1)
+#pragma unroll
+                            for (int k = 0; k < 16; ++k) v16[k] += __shfl_xor(v16[k], off, 64);
+                        if (lane < CH) {
+#pragma unroll
+                            for (int k = 0; k < 16; ++k) red[(wave * CH + lane) * 16 + k] = v16[k];
+                        }
+                    }
+                    __syncthreads();
+                    if (tid < CH * 16) {
+                        float a = 0.f;
+                        if (s2 < nslots) a = (red[tid] + red[CH * 16 + tid]) + (red[2 * CH * 16 + tid] + red[3 * CH * 16 + tid]);
+                        const int cg = tid >> 4, k = tid & 15;
+                        const int c = n0 + cg * 8 + (k & 7);
+                        if (c < Cout) out[((size_t)s2 * Cout + c) * 2 + (k >> 3)] = a;
+                    }
+                    __syncthreads();
                 }
-                __syncthreads();
             }
         }
+#if FNET_CONV_STAMPS
+        STAMP(st_b);
+        st_epi += st_b - st_a;
+#endif
         if (!have_next) break;
         cur = nxt;
     }
+#if FNET_CONV_STAMPS
+    if (tid == 0 && stamps) {
+        atomicAdd((unsigned long long*)stamps + 0, (unsigned long long)st_bar);
+        atomicAdd((unsigned long long*)stamps + 1, (unsigned long long)st_loop);
+        atomicAdd((unsigned long long*)stamps + 2, (unsigned long long)st_epi);
+        atomicAdd((unsigned long long*)stamps + 3, (unsigned long long)(__builtin_amdgcn_s_memtime() - st_t0));
+        atomicAdd((unsigned long long*)stamps + 4, 1ull);
+    }
+#endif
+#undef STAMP
 }
 
 // ------------------------------------------------------------------------------------------- weight gradient
@@ -591,8 +656,6 @@ int fnet_conv3x3_mfma(const FnetOp& op, hipStream_t st) {
     FNET_CHECK_ARG(op.i[3] % 8 == 0 && op.i[4] % 8 == 0 && op.i[6] % 8 == 0 && op.i[7] % 8 == 0);
     FNET_CHECK_ARG(op.i[4] + Cin <= op.i[3] && op.i[7] + Cout <= op.i[6]);
     FNET_CHECK_ARG(op.p[0] && op.p[1] && op.p[3] && (op.p[0] % 16) == 0 && (op.p[1] % 16) == 0 && (op.p[3] % 16) == 0);
-    const int TN = Cout > 32 ? 64 : 32;
-    const int rinp = (TM + 2 * Wp + 2 + 31) / 32 * 32;
     // optional fused InstanceNorm partial sums: p[4] = scratch (i[9] floats), i[10] = H (W = Wp - 2)
     float* stats_part = (float*)op.p[4];
     const int H = op.i[10], W = Wp - 2;
@@ -600,17 +663,6 @@ int fnet_conv3x3_mfma(const FnetOp& op, hipStream_t st) {
         FNET_CHECK_ARG(H >= 1 && W >= 1 && (H + 2) * Wp >= TM && Npix % ((H + 2) * Wp) == 0);
         FNET_CHECK_ARG((long long)((Npix + TM - 1) / TM) * 4 * Cout <= (long long)op.i[9]);
     }
-    // one stage buffer: weights + input run, and big enough for the output tile (+ 2 KB of statistics scratch)
-    size_t bufsz = (size_t)rinp * 32 + (size_t)9 * TN * 32;
-    const size_t need = (size_t)TM * TN * 2 + 4 * (TN / 8) * 16 * 4;
-    if (bufsz < need) bufsz = need;
-    const size_t lds = 2 * bufsz;
-    FNET_CHECK_ARG(lds <= 160 * 1024);
-    // the DMA window offsets are 32-bit
-    FNET_CHECK_ARG((long long)(rinp + 2) * op.i[3] * 2 < (1ll << 30));
-    const int n_mtiles = (Npix + TM - 1) / TM, n_ntiles = (Cout + TN - 1) / TN;
-    const int n_items = 8 * ((n_mtiles + 7) / 8) * n_ntiles;
-    // persistent grid: two blocks per CU (LDS allows 2 at <= 80 KB each), a multiple of 8 for the XCD mapping
     int cus = 256;
     {
         int dev = 0;
@@ -618,7 +670,34 @@ int fnet_conv3x3_mfma(const FnetOp& op, hipStream_t st) {
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
             cus = prop.multiProcessorCount;
     }
-    int nblk = (lds <= 80 * 1024 ? 2 : 1) * cus;
+    // Tile shape.  Small: 256 px x {32,64} couts, 4 waves, two blocks per CU.  Big: 512 px x {64,128} couts, 8 waves, one block
+    // per CU: 1.6-2.3x fewer staged bytes per FLOP, taken when the layer has enough big tiles to keep every CU busy for at
+    // least ~3 rounds (a partial last round of big tiles costs more than it saves on the small layers).
+    // FNET_CONV_TILE=small|big forces one shape (tuning / tools/conv_bench.py).
+    static const int forced = [] { const char* e = getenv("FNET_CONV_TILE"); return !e ? 0 : (e[0] == 's' ? 1 : (e[0] == 'b' ? 2 : 0)); }();
+    bool big = false;
+    if ((FNET_CONV_STAMPS || !stats_part) && Cout > 32) {
+        const int tn_b = Cout > 64 ? 128 : 64;
+        const long long items_b = (long long)((Npix + 511) / 512) * ((Cout + tn_b - 1) / tn_b);
+        big = items_b >= 3ll * cus;
+        if (forced) big = forced == 2;
+    }
+    const int tm = big ? 512 : TM;
+    const int TN = big ? (Cout > 64 ? 128 : 64) : (Cout > 32 ? 64 : 32);
+    const int rinp = (tm + 2 * Wp + 2 + 31) / 32 * 32;
+    // one stage buffer: weights + input run, and big enough for one output slice (+ 2 KB of statistics scratch)
+    size_t bufsz = (size_t)rinp * 32 + (size_t)9 * TN * 32;
+    const int tne = TN > 64 ? 64 : TN;
+    const size_t need = (size_t)tm * tne * 2 + 4 * (tne / 8) * 16 * 4;
+    if (bufsz < need) bufsz = need;
+    const size_t lds = 2 * bufsz;
+    FNET_CHECK_ARG(lds <= 160 * 1024);
+    // the DMA window offsets are 32-bit
+    FNET_CHECK_ARG((long long)(rinp + 2) * op.i[3] * 2 < (1ll << 30));
+    const int n_mtiles = (Npix + tm - 1) / tm, n_ntiles = (Cout + TN - 1) / TN;
+    const int n_items = 8 * ((n_mtiles + 7) / 8) * n_ntiles;
+    // persistent grid: one (big) or two (small; LDS allows 2 at <= 80 KB each) blocks per CU, a multiple of 8 for the XCD mapping
+    int nblk = ((!big && lds <= 80 * 1024) ? 2 : 1) * cus;
     nblk = (nblk + 7) / 8 * 8;
     if (nblk > n_items) nblk = n_items;
     const dim3 grid(nblk);
@@ -626,17 +705,18 @@ int fnet_conv3x3_mfma(const FnetOp& op, hipStream_t st) {
     const bf16_t* Wk = (const bf16_t*)op.p[1];
     const float* bias = (const float*)op.p[2];
     bf16_t* dst = (bf16_t*)op.p[3];
-    if (TN == 64) {
-        int rc = set_lds_limit(k_conv3x3_dma<64>, lds);
-        if (rc) return rc;
-        hipLaunchKernelGGL(k_conv3x3_dma<64>, grid, dim3(kThreads), lds, st, src, Wk, bias, dst, Npix, Wp, Cin, op.i[3], op.i[4], Cout,
-                           op.i[6], op.i[7], n_mtiles, n_ntiles, rinp, (int)bufsz, stats_part, H, W);
-    } else {
-        int rc = set_lds_limit(k_conv3x3_dma<32>, lds);
-        if (rc) return rc;
-        hipLaunchKernelGGL(k_conv3x3_dma<32>, grid, dim3(kThreads), lds, st, src, Wk, bias, dst, Npix, Wp, Cin, op.i[3], op.i[4], Cout,
-                           op.i[6], op.i[7], n_mtiles, n_ntiles, rinp, (int)bufsz, stats_part, H, W);
+#define FNET_LAUNCH_CONV(TN_, NW_)                                                                                                   \
+    {                                                                                                                                \
+        int rc = set_lds_limit(k_conv3x3_dma<TN_, NW_>, lds);                                                                        \
+        if (rc) return rc;                                                                                                           \
+        hipLaunchKernelGGL((k_conv3x3_dma<TN_, NW_>), grid, dim3(NW_ * 64), lds, st, src, Wk, bias, dst, Npix, Wp, Cin, op.i[3],     \
+                           op.i[4], Cout, op.i[6], op.i[7], n_mtiles, n_ntiles, rinp, (int)bufsz, stats_part, H, W);                \
     }
+    if (big && TN == 128) FNET_LAUNCH_CONV(128, 8)
+    else if (big) FNET_LAUNCH_CONV(64, 8)
+    else if (TN == 64) FNET_LAUNCH_CONV(64, 4)
+    else FNET_LAUNCH_CONV(32, 4)
+#undef FNET_LAUNCH_CONV
     FNET_LAUNCH_CHECK();
     return FNET_OK;
 }

@@ -1,5 +1,9 @@
 """MFMA convolution / weight-gradient kernels on multi-tile shapes (several pixel tiles, N tiles, channel slices of wider
 buffers, partial tiles, images straddling tile boundaries) against the CPU twin, through the C ABI."""
+import os
+import subprocess
+import sys
+
 import numpy as np
 import pytest
 import torch
@@ -63,4 +67,24 @@ def test_mfma_conv_and_wgrad(shape):
 def test_ref_conv_and_wgrad(dtype):
     pb, ops = _mk(2, 20, 12, 32, 40, 96, 32, 64, 16, dtype, "ref")
     failures = lockstep(pb, ops)
+    assert not failures, "\n".join(failures)
+
+
+def test_big_tile_kernels_on_every_shape():
+    """The 512-pixel x 64/128-cout tile kernels (8 waves, one block per CU) are chosen by the launcher only for layers with
+    >= 3 rounds of big tiles; FNET_CONV_TILE=big (read once per process) forces them, so the shapes above -- partial tiles,
+    channel slices, images straddling tiles -- run again in a child process with that setting."""
+    if os.environ.get("FNET_CONV_TILE"):
+        pytest.skip("already inside the forced-tile child")
+    env = dict(os.environ, FNET_CONV_TILE="big")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k", "test_mfma_conv_and_wgrad",
+                        "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert f"{len(SHAPES)} passed" in r.stdout, r.stdout[-2000:]
+
+
+def test_big_tile_selected_at_full_size():
+    # 24 images of 128x128 with 64 -> 128 channels: 793 big tiles >= 3 x 256 CUs, so the launcher takes the 512 x 128 kernel itself
+    pb, ops = _mk(24, 128, 128, 64, 128, 64, 0, 128, 0, "bf16", "mfma")
+    failures = lockstep(pb, ops[:1])
     assert not failures, "\n".join(failures)

@@ -25,7 +25,8 @@ def build():
         d = os.path.join(b.LIBDIR, f"abl{v}")
         os.makedirs(d, exist_ok=True)
         obj = os.path.join(d, "fnet_conv_mfma.o")
-        subprocess.run([b._hipcc(), *b.FLAGS, f"-DFNET_CONV_ABLATE={v}", "-c", os.path.join(b.CSRC, "fnet_conv_mfma.hip"), "-o", obj], check=True)
+        flag = "-DFNET_CONV_STAMPS=1" if v == 9 else f"-DFNET_CONV_ABLATE={v}"       # variant 9 = in-kernel cycle stamps
+        subprocess.run([b._hipcc(), *b.FLAGS, flag, "-c", os.path.join(b.CSRC, "fnet_conv_mfma.hip"), "-o", obj], check=True)
         objs = [obj if s == "fnet_conv_mfma.hip" else os.path.join(b.LIBDIR, s.replace(".hip", ".o")) for s in b.SOURCES]
         subprocess.run([b._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", os.path.join(d, "libfluidnet_hip.so"), *objs], check=True)
         print("built", d)
@@ -70,12 +71,13 @@ def run(B=64, reps=20):
             ms = t.elapsed_ms() / reps
             out.append(f"{name} {ms * 1e3:7.1f} us {fl / ms / 1e9:6.0f} TF")
             if name == "conv+stats" and os.environ.get("FNET_STAMPS"):
+                # library built with -DFNET_CONV_STAMPS (tools/conv_bench.py build with STAMPS=1): cycles of wave 0 per block
                 sc.tensor.zero_()
                 rt.run_ops(one)
                 torch.cuda.synchronize()
                 c = sc.tensor[:16].view(torch.int64).cpu().numpy()
                 nb = max(1, int(c[4]))
-                out.append("cycles/block prologue %d loop %d outtile %d store %d (blocks %d)" % (c[0] / nb, c[1] / nb, c[2] / nb, c[3] / nb, nb))
+                out.append("cycles/block barrier-wait %d taps %d epilogue %d total %d (blocks %d)" % (c[0] / nb, c[1] / nb, c[2] / nb, c[3] / nb, nb))
         print(f"H={H:4d} {cin:4d}->{cout:4d}: " + " | ".join(out), flush=True)
 
 

@@ -49,11 +49,21 @@ def c2_loss(R):
 def dist_setup(n):
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # FNET_DIST_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks (ranks then share devices and the
+    # all-reduces go through the host); production is one rank per GPU over nccl (= RCCL on ROCm)
+    backend = os.environ.get("FNET_DIST_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and local >= ndev:
+        raise SystemExit(f"LOCAL_RANK {local} but only {ndev} GPUs visible: one rank per GPU")
+    local = local % max(ndev, 1)
     torch.cuda.set_device(local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     return rank, world, local
 
 
@@ -81,7 +91,12 @@ class TrainStepper:
         if world > 1:
             import torch.distributed as dist
             self.dist = dist
-            dist.broadcast(self.model.flat_params, 0)
+            if dist.get_backend() == "gloo":            # rehearsal mode: through the host
+                h = self.model.flat_params.detach().cpu()
+                dist.broadcast(h, 0)
+                self.model.flat_params.data.copy_(h)
+            else:
+                dist.broadcast(self.model.flat_params, 0)
 
     def step(self):
         self.t += 1
@@ -234,7 +249,7 @@ def main():
             st.step()
         barrier(world)
         dt = time.perf_counter() - t0
-        tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        tmax = torch.tensor([dt], device="cuda" if world == 1 or st.dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         if world > 1:
             st.dist.all_reduce(tmax, op=st.dist.ReduceOp.MAX)
         dt = float(tmax.item())

@@ -42,9 +42,13 @@ def dp_train_step(plan, world: int, all_reduce: Optional[Callable] = None, run: 
 def torch_all_reduce(dist):
     """Adapter from torch.distributed (backend nccl = RCCL on ROCm, or gloo in the CPU tests) to dp_train_step's callback."""
     def f(t: torch.Tensor, op: str) -> None:
-        if op == "avg" and dist.get_backend() == "gloo":      # gloo has no AVG
-            dist.all_reduce(t, op=dist.ReduceOp.SUM)
-            t.div_(dist.get_world_size())
+        if dist.get_backend() == "gloo":                      # CPU tests / rehearsal: no AVG, and device tensors go through the host
+            h = t.detach().cpu() if t.is_cuda else t
+            dist.all_reduce(h, op=dist.ReduceOp.SUM)
+            if op == "avg":
+                h.div_(dist.get_world_size())
+            if t.is_cuda:
+                t.copy_(h)
         else:
             dist.all_reduce(t, op=dist.ReduceOp.AVG if op == "avg" else dist.ReduceOp.SUM)
     return f

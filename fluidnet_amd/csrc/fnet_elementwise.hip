@@ -529,6 +529,35 @@ __global__ __launch_bounds__(256) void k_affine_grad(const float2* S, float* dga
     }
 }
 
+// the same for up to 7 norm layers per launch (blockIdx.y = layer): a backward pass has 26 of these 4-microsecond kernels
+struct AffineUnits {
+    int n;
+    int s_off[7], C[7], dg_off[7], db_off[7];
+};
+__global__ __launch_bounds__(256) void k_affine_grad_multi(const float* Sbase, float* grads, AffineUnits u, int B) {
+    __shared__ float2 red[kThreads];
+    const int j = blockIdx.y;
+    const int C = u.C[j];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+    if (blockIdx.x * 64 >= C) return;             // uniform per block
+    const float2* S = reinterpret_cast<const float2*>(Sbase + u.s_off[j]);
+    float a = 0.f, b = 0.f;
+    if (c < C) {
+#pragma unroll 8
+        for (int n = g; n < B; n += 4) {
+            const float2 s = S[(size_t)n * C + c];
+            a += s.x; b += s.y;
+        }
+    }
+    red[threadIdx.x] = make_float2(a, b);
+    __syncthreads();
+    if (g == 0 && c < C) {
+        const float2 r1 = red[threadIdx.x + 64], r2 = red[threadIdx.x + 128], r3 = red[threadIdx.x + 192];
+        grads[u.db_off[j] + c] += (a + r1.x) + (r2.x + r3.x);
+        grads[u.dg_off[j] + c] += (b + r1.y) + (r2.y + r3.y);
+    }
+}
+
 // ------------------------------------------------------------------ FOLD_SUM: dst = fold(g1)+fold(g2) interior, 0 ring
 template <typename T>
 __global__ __launch_bounds__(256) void k_fold_sum(const T* g1, const T* g2, T* dst, int B, int H, int W, int C, int ldc_g1, int coff_g1,
@@ -814,6 +843,8 @@ int fnet_op_in_stats(const FnetOp& op, hipStream_t st) {
         int chunks;
         const int per = cg_pixels_per_block(H * W, B, C, &chunks, 768);
         FNET_CHECK_ARG((long long)B * chunks * C * 2 <= (long long)op.i[6]);
+        // (finalising inside the same launch -- last block of an image, agent-scope fences -- was built and measured: the
+        // release fence in every block costs ~70 us per launch against 4.7 us for this second kernel)
         hipLaunchKernelGGL(k_in_stats_part<bf16_t>, dim3(chunks, B), dim3(kThreads), 0, st, (const bf16_t*)op.p[0], (float*)op.p[2], H, W, C,
                            op.i[4], op.i[5], per);
         hipLaunchKernelGGL(k_in_finalize, dim3((B * C + kThreads - 1) / kThreads), dim3(kThreads), 0, st, (const float2*)op.p[2],
@@ -899,6 +930,25 @@ int fnet_op_affine_grad(const FnetOp& op, hipStream_t st) {
     FNET_CHECK_ARG(B > 0 && C > 0 && op.p[0] && op.p[1] && op.p[2]);
     hipLaunchKernelGGL(k_affine_grad, dim3((C + 63) / 64), dim3(kThreads), 0, st, (const float2*)op.p[0],
                        (float*)op.p[1], (float*)op.p[2], B, C);
+    FNET_LAUNCH_CHECK();
+    return FNET_OK;
+}
+
+// AFFINE_GRAD_MULTI  i: 0 B,1 n_units (<= 7), per unit u at 2+4u: S offset (floats),C,dgamma offset,dbeta offset (floats)
+//                    p: 0 S slab base,1 flat gradient buffer (+=)
+int fnet_op_affine_grad_multi(const FnetOp& op, hipStream_t st) {
+    const int B = op.i[0], n = op.i[1];
+    FNET_CHECK_ARG(B > 0 && n >= 1 && n <= 7 && op.p[0] && op.p[1] && (op.p[0] % 8) == 0);
+    AffineUnits u;
+    u.n = n;
+    int cmax = 0;
+    for (int j = 0; j < 7; ++j) {
+        const int k = j < n ? j : 0;
+        u.s_off[j] = op.i[2 + 4 * k]; u.C[j] = op.i[3 + 4 * k]; u.dg_off[j] = op.i[4 + 4 * k]; u.db_off[j] = op.i[5 + 4 * k];
+        FNET_CHECK_ARG(u.s_off[j] >= 0 && u.s_off[j] % 2 == 0 && u.C[j] > 0 && u.dg_off[j] >= 0 && u.db_off[j] >= 0);
+        if (u.C[j] > cmax) cmax = u.C[j];
+    }
+    hipLaunchKernelGGL(k_affine_grad_multi, dim3((cmax + 63) / 64, n), dim3(kThreads), 0, st, (const float*)op.p[0], (float*)op.p[1], u, B);
     FNET_LAUNCH_CHECK();
     return FNET_OK;
 }

@@ -224,6 +224,7 @@ class PlanBuilder:
         self.act = rt.ACT[cfg.act]
         self.bufs: List[Buf] = []
         self.s_slab: Optional[Buf] = None
+        self._affine_pending: list = []
         self.pool: Dict[Tuple, List[Buf]] = {}
         self.shapes = unet_param_shapes(cfg)
         self.offsets: "OrderedDict[str, int]" = OrderedDict()
@@ -468,8 +469,9 @@ class PlanBuilder:
         self.op(ops, "INACT_BWD_APPLY", [B, H, W, C, C, 0, C, 0, C, 0, self.act, u.drop_site, self.seed], f=[u.drop_p],
                 p=[Ref(G), Ref(u.raw), Ref(u.st), self.pref(u.norm + ".weight"), self.pref(u.norm + ".bias"), S, Ref(draw)],
                 tag=u.conv)
-        # separate tiny kernel: adding dgamma/dbeta from every block of the reduce kernel (2048 adders per address) cost more
-        self.op(ops, "AFFINE_GRAD", [B, C], p=[S, self.gref(u.norm + ".weight"), self.gref(u.norm + ".bias")], tag=u.norm)
+        # dgamma/dbeta: a separate tiny kernel (adding them from every block of the reduce kernel, hundreds of adders per
+        # address, cost more), batched over the layers of the backward pass by emit_backward (flush_affine)
+        self._affine_pending.append((S, C, self.gref(u.norm + ".weight"), self.gref(u.norm + ".bias"), u.norm))
         self.e_wgrad(ops, u.xin, PV(draw, C), u.conv)
         dx = None
         if need_dx:
@@ -524,6 +526,17 @@ class PlanBuilder:
         self.release(d)
         return dx
 
+    def flush_affine(self, ops) -> None:
+        """AFFINE_GRAD of every unit visited since the last flush, 7 per launch (their S sums all live in the current slab)."""
+        pend, self._affine_pending = self._affine_pending, []
+        for k in range(0, len(pend), 7):
+            grp = pend[k:k + 7]
+            iv = [self.B, len(grp)]
+            for (S, C, gw, gb, _) in grp:
+                assert S.buf is self.s_slab and gw.buf is self.grads and gb.buf is self.grads
+                iv += [S.off, C, gw.off, gb.off]
+            self.op(ops, "AFFINE_GRAD_MULTI", iv, p=[Ref(self.s_slab), Ref(self.grads)], tag="+".join(g[4] for g in grp))
+
     def emit_backward(self, ops, t: Tape, dpred: Buf, dx_out: Optional[Buf] = None, dx_channels: int = 6) -> None:
         """Adjoint of emit_forward.  Accumulates parameter gradients (dWk scratch for 3x3 weights, grads_flat for the
         rest); writes d(input) [B,dx_channels,H,W] fp32 into dx_out when given."""
@@ -569,6 +582,7 @@ class PlanBuilder:
         if need_dx:
             self.op(ops, "UNPACK_GRAD", [B, H, W, 16, dx_channels, self.pm], p=[g.pv.ref, Ref(dx_out)], tag="dx")
             self.release(g.pv.buf)
+        self.flush_affine(ops)
         if self.s_slab is not None and self.s_slab.shape[0] > s_begin:
             nbytes = (self.s_slab.shape[0] - s_begin) * 4
             z = OpRec(OPC["ZERO"], [nbytes & 0x7FFFFFFF, nbytes >> 31], [], [Ref(self.s_slab, s_begin)], self.dtype, "S_slab")

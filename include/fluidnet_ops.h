@@ -74,6 +74,9 @@
  *   i: 0 B, 1 H, 2 W, 3 C, 4 ldc_G, 5 coff_G, 6 ldc_raw, 7 coff_raw, 8 ldc_d, 9 coff_d, 10 act, 11 dropout site, 12 seed
  *   f: 0 drop_p; p: 0 G, 1 raw, 2 stats, 3 gamma, 4 beta, 5 S, 6 d_raw out P (ring = 0)
  * AFFINE_GRAD       i: 0 B, 1 C; p: 0 S float2[B][C], 1 dgamma (+=), 2 dbeta (+=)
+ * AFFINE_GRAD_MULTI AFFINE_GRAD of up to 7 norm layers in one launch (the plan batches a backward pass's 26 layers into 4)
+ *   i: 0 B, 1 n_units (<= 7), then per unit u at 2+4u: S offset (floats from p[0]), C, dgamma offset, dbeta offset (floats from p[1])
+ *   p: 0 S slab base, 1 flat gradient buffer base (+=)
  * FOLD_SUM          i: 0 B, 1 H, 2 W, 3 C, 4 ldc_g1, 5 coff_g1, 6 ldc_g2, 7 coff_g2, 8 ldc_d, 9 coff_d, 10 fold1, 11 fold2, 12 pm
  *                   p: 0 g1, 1 g2|0, 2 dst (interior = folded sum, ring = 0)
  * BIAS_GRAD         i: 0 B, 1 H, 2 W, 3 C, 4 ldc, 5 coff; p: 0 d P, 1 dbias (+=)

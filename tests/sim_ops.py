@@ -228,6 +228,15 @@ class Sim:
         self.flat(r.p[2])[:C] += S[:, :, 0].sum(0)
         self.flat(r.p[1])[:C] += S[:, :, 1].sum(0)
 
+    def op_AFFINE_GRAD_MULTI(self, r):
+        B, n = r.i[:2]
+        slab, grads = self.flat(r.p[0]), self.flat(r.p[1])
+        for j in range(n):
+            s_off, C, dg, db = r.i[2 + 4 * j: 6 + 4 * j]
+            S = slab[s_off: s_off + B * C * 2].view(B, C, 2)
+            grads[db: db + C] += S[:, :, 0].sum(0)
+            grads[dg: dg + C] += S[:, :, 1].sum(0)
+
     def op_FOLD_SUM(self, r):
         B, H, W, C, l1, c1, l2, c2, ld, cd, fold1, fold2, pm = r.i[:13]
         g = fold(self.rd(r.p[0], C, l1, c1), pm, fold1)

@@ -325,6 +325,100 @@ __global__ __launch_bounds__(256) void k_head_bwd(const float* dpred, const floa
     }
 }
 
+// ------------------------------------------------------------------ validation metrics (ml/training/metrics.py)
+// One pass over (pred, target, masks) for every sum the reference's metric functions need:
+//   m[0..2] sum (p_c - t_c)^2 per channel   (compute_per_channel_mse, metrics.py:7-12)
+//   m[3], m[4] sum |d/dx (p0 - t0)|, |d/dy ...|  (compute_gradient_l1, :24-38; unmasked means)
+//   m[5] sum div(vx,vy)^2                     (compute_divergence_norm, :41-51)
+//   m[6] sum vx^2 + vy^2                      (compute_kinetic_energy, :54-61)
+//   m[7] sum collider, m[8] sum density*collider   (compute_collider_violation, :64-78)
+//   m[9] sum emitter,  m[10] sum density*emitter   (compute_emitter_density_accuracy, :81-97)
+struct MetricArgs {
+    const float* pred;
+    Plane tgt, emit, coll;
+    int B, H, W, pm, stencil;
+    float dx;
+};
+__global__ __launch_bounds__(256) void k_metrics_reduce(MetricArgs a, double* sums) {
+    constexpr int NM = 11;
+    __shared__ double red[4 * NM];
+    const int HW = a.H * a.W, total = a.B * HW;
+    double s[NM];
+#pragma unroll
+    for (int k = 0; k < NM; ++k) s[k] = 0.0;
+    for (int idx = blockIdx.x * kThreads + threadIdx.x; idx < total; idx += gridDim.x * kThreads) {
+        const int n = idx / HW, r = idx - n * HW, y = r / a.W, x = r - y * a.W;
+        const float* P = a.pred + (size_t)n * 3 * HW;
+        const float* T = a.tgt.p + (size_t)n * a.tgt.bstride;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { const float d = P[c * HW + r] - T[c * HW + r]; s[c] += d * d; }
+        s[3] += fabsf(ddx(P, y, x, a.H, a.W, a.pm, a.stencil, a.dx) - ddx(T, y, x, a.H, a.W, a.pm, a.stencil, a.dx));
+        s[4] += fabsf(ddy(P, y, x, a.H, a.W, a.pm, a.stencil, a.dx) - ddy(T, y, x, a.H, a.W, a.pm, a.stencil, a.dx));
+        const float dv = ddx(P + HW, y, x, a.H, a.W, a.pm, a.stencil, a.dx) + ddy(P + 2 * HW, y, x, a.H, a.W, a.pm, a.stencil, a.dx);
+        s[5] += dv * dv;
+        const float vx = P[HW + r], vy = P[2 * HW + r];
+        s[6] += vx * vx + vy * vy;
+        const float co = a.coll.p[(size_t)n * a.coll.bstride + r], em = a.emit.p[(size_t)n * a.emit.bstride + r];
+        s[7] += co; s[8] += P[r] * co;
+        s[9] += em; s[10] += P[r] * em;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NM; ++k) s[k] = wave_sum_d(s[k]);
+    if (lane == 0)
+        for (int k = 0; k < NM; ++k) red[wave * NM + k] = s[k];
+    __syncthreads();
+    if (threadIdx.x < NM) {
+        const int k = threadIdx.x;
+        atomicAdd(sums + k, red[k] + red[NM + k] + red[2 * NM + k] + red[3 * NM + k]);
+    }
+}
+
+// SSIM of the density channel (compute_ssim_density, metrics.py:15-21 = torchmetrics' structural_similarity_index_measure with
+// its defaults: 11x11 Gaussian window, sigma 1.5, k1 0.01, k2 0.03, data_range 1; torchmetrics is NOT in this image, so this
+// follows its published algorithm and parity is unpinned).  The library reflect-pads by 5, filters, and then crops 5 pixels
+// per side before averaging, so only windows that lie fully inside the image count: m[11] += sum of the SSIM map over
+// y in [5, H-5), x in [5, W-5); the host divides by B*(H-10)*(W-10).
+__global__ __launch_bounds__(256) void k_ssim_density(const float* pred, Plane tgt, int B, int H, int W, double* sums) {
+    __shared__ double red[4];
+    __shared__ float g[11];
+    if (threadIdx.x < 11) {
+        float tot = 0.f;
+        for (int k = 0; k < 11; ++k) { const float d = (float)(k - 5) / 1.5f; tot += expf(-0.5f * d * d); }
+        const float d = (float)((int)threadIdx.x - 5) / 1.5f;
+        g[threadIdx.x] = expf(-0.5f * d * d) / tot;
+    }
+    __syncthreads();
+    const int h = H - 10, w = W - 10, hw = h * w, total = B * hw;
+    double acc = 0.0;
+    for (int idx = blockIdx.x * kThreads + threadIdx.x; idx < total; idx += gridDim.x * kThreads) {
+        const int n = idx / hw, r = idx - n * hw, y = r / w, x = r - y * w;      // window rows y..y+10, columns x..x+10
+        const float* P = pred + (size_t)n * 3 * H * W;
+        const float* T = tgt.p + (size_t)n * tgt.bstride;
+        float mp = 0.f, mt = 0.f, pp = 0.f, tt = 0.f, pt = 0.f;
+        for (int j = 0; j < 11; ++j) {
+            float rp = 0.f, rt = 0.f, rpp = 0.f, rtt = 0.f, rpt = 0.f;
+            const size_t o = (size_t)(y + j) * W + x;
+#pragma unroll
+            for (int i = 0; i < 11; ++i) {
+                const float p = P[o + i], t = T[o + i], wgt = g[i];
+                rp = fmaf(wgt, p, rp); rt = fmaf(wgt, t, rt);
+                rpp = fmaf(wgt, p * p, rpp); rtt = fmaf(wgt, t * t, rtt); rpt = fmaf(wgt, p * t, rpt);
+            }
+            const float wj = g[j];
+            mp = fmaf(wj, rp, mp); mt = fmaf(wj, rt, mt); pp = fmaf(wj, rpp, pp); tt = fmaf(wj, rtt, tt); pt = fmaf(wj, rpt, pt);
+        }
+        const float c1 = 0.01f * 0.01f, c2 = 0.03f * 0.03f;
+        const float mpp = mp * mp, mtt = mt * mt, mpt = mp * mt;
+        const float sp = fmaxf(pp - mpp, 0.f), st = fmaxf(tt - mtt, 0.f), spt = pt - mpt;
+        acc += (double)(((2.f * mpt + c1) * (2.f * spt + c2)) / ((mpp + mtt + c1) * (sp + st + c2)));
+    }
+    acc = wave_sum_d(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(sums + 11, red[0] + red[1] + red[2] + red[3]);
+}
+
 inline LossArgs make_loss_args(const FnetOp& op) {
     LossArgs a;
     a.pred = (const float*)op.p[0];
@@ -382,6 +476,33 @@ int fnet_op_loss_grad(const FnetOp& op, hipStream_t st) {
     hipLaunchKernelGGL(k_loss_grad, dim3((total + kThreads - 1) / kThreads), dim3(kThreads), 0, st, a, (const double*)op.p[5],
                        (const double*)op.p[6], (const float*)op.p[7], op.i[11], (const float*)op.p[8], (float*)op.p[9], op.i[10],
                        op.f[1], op.f[2], op.f[3], op.f[4], op.f[5]);
+    FNET_LAUNCH_CHECK();
+    return FNET_OK;
+}
+
+// METRICS  i: 0 B,1 H,2 W,3 tgt bstride,4 emit bstride,5 coll bstride,6 pm,7 stencil,8 flags (bit0: SSIM); f: 0 dx
+//          p: 0 pred [B,3,H,W],1 target,2 emitter,3 collider,4 sums double[16] (zeroed by the caller; slots above)
+int fnet_op_metrics(const FnetOp& op, hipStream_t st) {
+    const int B = op.i[0], H = op.i[1], W = op.i[2];
+    FNET_CHECK_ARG(B > 0 && H >= 2 && W >= 2 && (long long)B * H * W < (1ll << 31));
+    FNET_CHECK_ARG(op.p[0] && op.p[1] && op.p[2] && op.p[3] && op.p[4]);
+    FNET_CHECK_ARG(op.i[3] >= 3 * H * W && op.i[4] >= H * W && op.i[5] >= H * W);
+    FNET_CHECK_ARG(op.i[6] >= 0 && op.i[6] <= 3 && op.i[7] >= 0 && op.i[7] <= 1 && op.f[0] > 0.f);
+    MetricArgs a;
+    a.pred = (const float*)op.p[0];
+    a.tgt = {(const float*)op.p[1], op.i[3]};
+    a.emit = {(const float*)op.p[2], op.i[4]};
+    a.coll = {(const float*)op.p[3], op.i[5]};
+    a.B = B; a.H = H; a.W = W; a.pm = op.i[6]; a.stencil = op.i[7]; a.dx = op.f[0];
+    int blocks = (B * H * W + kThreads * 4 - 1) / (kThreads * 4);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_metrics_reduce, dim3(blocks), dim3(kThreads), 0, st, a, (double*)op.p[4]);
+    if (op.i[8] & 1) {
+        FNET_CHECK_ARG(H > 10 && W > 10);            // the library's crop leaves nothing otherwise
+        int sb = (B * (H - 10) * (W - 10) + kThreads - 1) / kThreads;
+        if (sb > 4096) sb = 4096;
+        hipLaunchKernelGGL(k_ssim_density, dim3(sb), dim3(kThreads), 0, st, a.pred, a.tgt, B, H, W, (double*)op.p[4]);
+    }
     FNET_LAUNCH_CHECK();
     return FNET_OK;
 }

@@ -30,6 +30,7 @@ from .dp import dp_train_step, torch_all_reduce
 from .early_stopping import EarlyStopping
 from .optim import FusedClipAdam
 from .physics_loss import PhysicsAwareLoss
+from .metrics import MetricsTracker, validation_metrics
 
 
 class _Scheduler:
@@ -206,21 +207,29 @@ class Trainer:
         return {k: v / max(n, 1) for k, v in acc.items()}
 
     def validate(self) -> Dict[str, float]:
+        """ml/training/trainer.py:206-310: averaged loss terms + the validation metrics of the last prediction (one METRICS
+        kernel pass and one host copy per batch instead of the reference's ten .item() syncs)."""
         self.model.eval()
         acc: Dict[str, float] = {}
+        tracker = MetricsTracker()
         n = 0
+        pl = self.config.physics_loss
         with torch.no_grad():
             for batch in self.val_loader:
                 batch = self._to_device(batch)
                 if len(batch) == 3:
-                    _, d, _ = self._compute_rollout_loss(*batch)
+                    _, d, outputs = self._compute_rollout_loss(*batch)
+                    target, emitter, collider = batch[1][:, -1], batch[2][:, -1, 0], batch[2][:, -1, 1]
                 else:
                     outputs = self.model(batch[0])
                     _, d = self.criterion(outputs, batch[1], batch[0])
+                    target, emitter, collider = batch[1], batch[0][:, 4], batch[0][:, 5]
                 n += 1
                 for k, v in d.items():
                     acc[k] = acc.get(k, 0.0) + v
-        return {k: v / max(n, 1) for k, v in acc.items()}
+                tracker.update(validation_metrics(outputs, target, emitter, collider, dx=pl.grid_spacing, padding_mode=self.config.padding_mode,
+                                                  mode=pl.stencil_mode, expected_injection=0.8))
+        return {**{k: v / max(n, 1) for k, v in acc.items()}, **tracker.compute_averages()}
 
     def train(self) -> None:
         for epoch in range(self.config.epochs):

@@ -109,6 +109,7 @@ enum FnetOpCode {
     FNET_OP_UNPREP_WGRAD = 27,
     FNET_OP_STENCIL = 28,
     FNET_OP_AFFINE_GRAD_MULTI = 29,
+    FNET_OP_METRICS = 30,
     FNET_OP_COUNT_
 };
 

@@ -96,6 +96,13 @@
  * ADAM              <- clip_grad_norm_'s scaling + torch.optim.Adam.step (no amsgrad, no weight decay; trainer.py:164-195)
  *   i: 0 n & 0x7fffffff, 1 n >> 31; f: 0 lr, 1 beta1, 2 beta2, 3 eps, 4 1-beta1^t, 5 sqrt(1-beta2^t),
  *      6 max_norm (<= 0: no clip), 7 grad scale; p: 0 params, 1 grads, 2 exp_avg, 3 exp_avg_sq, 4 |0 sum of squares
+ * METRICS           <- the validation metrics of ml/training/metrics.py:7-97 in one pass (used by Trainer.validate,
+ *                      ml/training/trainer.py:256-302); SSIM follows torchmetrics' published defaults (parity unpinned:
+ *                      the library is not in the image)
+ *   i: 0 B, 1 H, 2 W, 3 target bstride, 4 emitter bstride, 5 collider bstride, 6 pm, 7 stencil, 8 flags (bit0 SSIM); f: 0 dx
+ *   p: 0 pred [B,3,H,W], 1 target, 2 emitter, 3 collider, 4 sums double[16] (zero first): [0..2] squared error per
+ *      channel, [3],[4] |d/dx|,|d/dy| of the density error, [5] divergence^2, [6] vx^2+vy^2, [7] collider cells,
+ *      [8] density in collider, [9] emitter cells, [10] density in emitter, [11] SSIM map sum over the cropped interior
  * COPY_PLANES       <- the autoregressive state hand-off (ml/scripts/simple_infer.py:259-260)
  *   i: 0 B, 1 count, 2 src batch stride, 3 dst batch stride (floats); p: 0 src, 1 dst
  * STENCIL           <- compute_spatial_gradients / compute_divergence (physics_loss.py:19-91)

@@ -524,6 +524,79 @@ def rollout_infer(p, cfg, emitter: Tensor, collider: Tensor, frames: int, *, sta
 
 
 # --------------------------------------------------------------------------
+# validation metrics (ml/training/metrics.py:7-97)
+# PARITY UNPINNED by execution: the reference module imports torchmetrics at load, which is not installed offline, so no
+# fixture could be generated from it.  Everything except SSIM is a mean/sum over the stencil functions above (which ARE
+# pinned by the physics-loss fixtures); SSIM restates torchmetrics' structural_similarity_index_measure defaults
+# (gaussian 11x11, sigma 1.5, k1 0.01, k2 0.03, reflect pad -> depthwise conv -> crop pad -> mean).
+# --------------------------------------------------------------------------
+def per_channel_mse(pred: Tensor, target: Tensor) -> Dict[str, float]:                       # metrics.py:7-12
+    return {"mse_density": float(((pred[:, 0] - target[:, 0]) ** 2).mean()), "mse_velx": float(((pred[:, 1] - target[:, 1]) ** 2).mean()),
+            "mse_vely": float(((pred[:, 2] - target[:, 2]) ** 2).mean())}
+
+
+def ssim_density(pred: Tensor, target: Tensor, data_range: float = 1.0) -> float:             # metrics.py:15-21
+    p, t = pred[:, 0:1].double(), target[:, 0:1].double()
+    sigma, ks = 1.5, int(3.5 * 1.5 + 0.5) * 2 + 1
+    pad = (ks - 1) // 2
+    dist = torch.arange((1 - ks) / 2, (1 + ks) / 2, 1, dtype=torch.float64)
+    g = torch.exp(-((dist / sigma) ** 2) / 2)
+    g = (g / g.sum())[None]
+    kernel = (g.t() @ g)[None, None]
+    c1, c2 = (0.01 * data_range) ** 2, (0.03 * data_range) ** 2
+    p = F.pad(p, (pad, pad, pad, pad), mode="reflect")
+    t = F.pad(t, (pad, pad, pad, pad), mode="reflect")
+    out = F.conv2d(torch.cat((p, t, p * p, t * t, p * t)), kernel)
+    mu_p, mu_t, e_pp, e_tt, e_pt = out.split(p.shape[0])
+    s_pp = torch.clamp(e_pp - mu_p ** 2, min=0.0)
+    s_tt = torch.clamp(e_tt - mu_t ** 2, min=0.0)
+    s_pt = e_pt - mu_p * mu_t
+    full = ((2 * mu_p * mu_t + c1) * (2 * s_pt + c2)) / ((mu_p ** 2 + mu_t ** 2 + c1) * (s_pp + s_tt + c2))
+    idx = full[..., pad:-pad, pad:-pad]
+    return float(idx.reshape(idx.shape[0], -1).mean(-1).mean())
+
+
+def gradient_l1(density_pred: Tensor, density_target: Tensor, dx=1.0, dy=1.0, padding_mode="zeros", mode="central") -> float:   # :24-38
+    gpx, gpy = compute_spatial_gradients(density_pred, dx, dy, padding_mode, mode)
+    gtx, gty = compute_spatial_gradients(density_target, dx, dy, padding_mode, mode)
+    return float((gpx - gtx).abs().mean()) + float((gpy - gty).abs().mean())
+
+
+def divergence_norm(velx: Tensor, vely: Tensor, dx=1.0, dy=1.0, padding_mode="zeros", mode="central") -> float:                 # :41-51
+    return float(torch.sqrt((compute_divergence(velx, vely, dx, dy, padding_mode, mode) ** 2).mean()))
+
+
+def kinetic_energy(velx: Tensor, vely: Tensor) -> float:                                       # :54-61
+    return 0.5 * float((velx ** 2 + vely ** 2).sum())
+
+
+def collider_violation(density: Tensor, collider_mask: Tensor, eps: float = 1e-8) -> float:    # :64-78
+    n = collider_mask.sum()
+    if n < eps:
+        return 0.0
+    return float((density * collider_mask).sum() / (n + eps))
+
+
+def emitter_density_accuracy(density: Tensor, emitter_mask: Tensor, expected_injection: float = 0.8, eps: float = 1e-8) -> float:  # :81-97
+    n = emitter_mask.sum()
+    if n < eps:
+        return 0.0
+    return float(((density * emitter_mask).sum() / (n + eps) - expected_injection).abs())
+
+
+def validation_metrics(outputs, target, emitter, collider, dx, padding_mode, mode) -> Dict[str, float]:
+    """The batch_metrics dict of Trainer.validate (ml/training/trainer.py:270-300)."""
+    d = per_channel_mse(outputs, target)
+    d["divergence_norm"] = divergence_norm(outputs[:, 1], outputs[:, 2], dx, dx, padding_mode, mode)
+    d["kinetic_energy"] = kinetic_energy(outputs[:, 1], outputs[:, 2])
+    d["collider_violation"] = collider_violation(outputs[:, 0], collider)
+    d["emitter_density_accuracy"] = emitter_density_accuracy(outputs[:, 0], emitter, 0.8)
+    d["ssim_density"] = ssim_density(outputs, target)
+    d["gradient_l1"] = gradient_l1(outputs[:, 0], target[:, 0], dx, dx, padding_mode, mode)
+    return d
+
+
+# --------------------------------------------------------------------------
 # dataset sample layout (ml/dataset/npz_sequence.py:68-75,115-212,349-433; augmentations.py:4-35)
 # --------------------------------------------------------------------------
 def build_indices(frame_counts: List[int], rollout_steps: int, stride: int, offset: int = 0) -> List[Tuple[int, int]]:

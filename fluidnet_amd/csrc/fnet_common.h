@@ -260,6 +260,7 @@ FNET_DECL_OP(fnet_op_inact_bwd_apply);
 FNET_DECL_OP(fnet_op_affine_grad);
 FNET_DECL_OP(fnet_op_affine_grad_multi);
 FNET_DECL_OP(fnet_op_metrics);
+FNET_DECL_OP(fnet_op_gather_batch);
 FNET_DECL_OP(fnet_op_fold_sum);
 FNET_DECL_OP(fnet_op_bias_grad);
 FNET_DECL_OP(fnet_op_zero_insert);

@@ -62,6 +62,45 @@ __global__ __launch_bounds__(256) void k_pack_input(PackArgs a, T* dst, int B, i
     }
 }
 
+// ------------------------------------------------------------------ GATHER_BATCH
+// Builds the dataset's (x0, y_seq, masks) tuples (ml/dataset/npz_sequence.py:349-433) for B samples straight from the
+// HBM-resident sequence store, with the flip augmentation of ml/dataset/augmentations.py:20-35 (mirror the width axis,
+// negate velx) applied on the fly.  grid = (pixel blocks, output planes, B); plane p of a sample:
+//   p < 6            x0: density_t, velx_t, velz_t, density_{t-1}, emitter_t, collider_t
+//   p < 6 + 3K       y_seq[k][c] = field c at t+1+k
+//   else             masks[j][m] = emitter/collider at t + mask_first + j
+__global__ __launch_bounds__(256) void k_gather_batch(const float* __restrict__ frames, const int* __restrict__ index, const int* __restrict__ flip,
+                                                      float* __restrict__ x0, float* __restrict__ y, float* __restrict__ masks, int H, int W, int K,
+                                                      int Km, int mask_first, int Tt) {
+    const int HW = H * W, r = blockIdx.x * kThreads + threadIdx.x;
+    if (r >= HW) return;
+    const int n = blockIdx.z, p = blockIdx.y, t = index[n], fl = flip[n];
+    int field, dt;
+    float* dst;
+    if (p < 6) {
+        field = p < 3 ? p : (p == 3 ? 0 : p - 1);         // 3 -> density (of t-1), 4 -> emitter (field 3), 5 -> collider (field 4)
+        dt = p == 3 ? -1 : 0;
+        dst = x0 + ((size_t)n * 6 + p) * HW;
+    } else if (p < 6 + 3 * K) {
+        const int q = p - 6, k = q / 3;
+        field = q - 3 * k;
+        dt = 1 + k;
+        dst = y + ((size_t)n * K * 3 + q) * HW;
+    } else {
+        const int q = p - 6 - 3 * K, j = q >> 1;
+        field = 3 + (q & 1);
+        dt = mask_first + j;
+        dst = masks + ((size_t)n * Km * 2 + q) * HW;
+    }
+    int f = t + dt;
+    f = f < 0 ? 0 : (f >= Tt ? Tt - 1 : f);                // the loader only hands out valid (sequence, t) pairs; never fault
+    const int yy = r / W, xx = r - yy * W;
+    const int sx = fl ? W - 1 - xx : xx;
+    float v = frames[((size_t)field * Tt + f) * HW + (size_t)yy * W + sx];
+    if (fl && field == 1) v = -v;
+    dst[r] = v;
+}
+
 // ------------------------------------------------------------------ channel-group thread mapping ("cg kernels")
 // The norm/activation kernels below give every thread a FIXED group of 8 channels (cg = tid % groups) and let it walk
 // pixels with stride ppi = 256 / groups, so the per-channel constants (mean, rstd, gamma, beta, dropout multiplier, the
@@ -1050,6 +1089,20 @@ int fnet_op_unpack_grad(const FnetOp& op, hipStream_t st) {
     FNET_CHECK_ARG(B > 0 && H >= 2 && W >= 2 && ldc % 8 == 0 && nch > 0 && nch <= ldc && op.p[0] && op.p[1]);
     DISPATCH_T(op.dtype, hipLaunchKernelGGL(k_unpack_grad<T>, row_grid(B * H, W), dim3(kThreads), 0, st, (const T*)op.p[0],
                                             (float*)op.p[1], B, H, W, ldc, nch, op.i[5]));
+    FNET_LAUNCH_CHECK();
+    return FNET_OK;
+}
+
+// GATHER_BATCH  i: 0 B,1 H,2 W,3 K,4 Km,5 mask_first,6 Ttotal; p: 0 frames fp32 [5][Ttotal][H][W] (density, velx, velz, emitter,
+//               collider),1 frame index int32[B],2 flip int32[B],3 x0 [B,6,H,W],4 y_seq [B,K,3,H,W],5 masks [B,Km,2,H,W]
+int fnet_op_gather_batch(const FnetOp& op, hipStream_t st) {
+    const int B = op.i[0], H = op.i[1], W = op.i[2], K = op.i[3], Km = op.i[4], Tt = op.i[6];
+    FNET_CHECK_ARG(B > 0 && H > 0 && W > 0 && K >= 1 && Km >= 1 && Km <= K + 1 && (op.i[5] == 0 || op.i[5] == 1) && Tt >= 3);
+    FNET_CHECK_ARG((long long)Tt * H * W < (1ll << 31) && (long long)(6 + 3 * K + 2 * Km) * H * W < (1ll << 31));
+    for (int k = 0; k < 6; ++k) FNET_CHECK_ARG(op.p[k] != 0);
+    const int planes = 6 + 3 * K + 2 * Km;
+    hipLaunchKernelGGL(k_gather_batch, dim3((H * W + kThreads - 1) / kThreads, planes, B), dim3(kThreads), 0, st, (const float*)op.p[0],
+                       (const int*)op.p[1], (const int*)op.p[2], (float*)op.p[3], (float*)op.p[4], (float*)op.p[5], H, W, K, Km, op.i[5], Tt);
     FNET_LAUNCH_CHECK();
     return FNET_OK;
 }

@@ -170,6 +170,10 @@ class Trainer:
         plan.x0.tensor.copy_(inputs)
         plan.y.tensor.copy_(targets)
         plan.masks.tensor.copy_(masks)
+        return self._run_plan(plan)
+
+    def _run_plan(self, plan: RolloutTrainPlan) -> Dict[str, float]:
+        """One optimisation step of a plan whose x0 / y / masks buffers are already filled."""
         self.optimizer.step_count += 1
         plan.set_adam_scalars(self.optimizer.param_groups[0]["lr"], self.optimizer.step_count)
         plan.set_dropout_seed(self.optimizer.step_count * 7919 + 13)
@@ -182,8 +186,27 @@ class Trainer:
     def _to_device(self, batch):
         return tuple(t.to(self.device, non_blocking=True) for t in batch)
 
+    def _train_epoch_hbm(self, loader) -> Dict[str, float]:
+        """HbmBatchLoader + plan engine: every batch is gathered by one kernel straight into the plan's input buffers (no host
+        batch, no copy), then the native K-step plan runs."""
+        st = loader.store
+        plan = self._plan_for(loader.B, st.H, st.W, loader.K, loader.Km)
+        if plan is None:
+            raise RuntimeError("no plan slot left for the HBM loader's batch shape (raise max_plans)")
+        acc: Dict[str, float] = {}
+        n = 0
+        for rows, flips in loader.batches():
+            loader.gather(rows, flips, plan.x0.tensor, plan.y.tensor, plan.masks.tensor)
+            d = self._run_plan(plan)
+            n += 1
+            for k, v in d.items():
+                acc[k] = acc.get(k, 0.0) + v
+        return {k: v / max(n, 1) for k, v in acc.items()}
+
     def train_epoch(self) -> Dict[str, float]:
         self.model.train()
+        if self.engine == "plan" and hasattr(self.train_loader, "gather") and hasattr(self.train_loader, "store"):
+            return self._train_epoch_hbm(self.train_loader)
         acc: Dict[str, float] = {}
         n = 0
         for batch in self.train_loader:
@@ -235,7 +258,9 @@ class Trainer:
         for epoch in range(self.config.epochs):
             t0 = time.time()
             ds = getattr(self.train_loader, "dataset", None)
-            if hasattr(ds, "set_epoch"):
+            if hasattr(self.train_loader, "set_epoch"):          # HbmBatchLoader: reshuffles and moves the dataset's stride offset
+                self.train_loader.set_epoch(epoch)
+            elif hasattr(ds, "set_epoch"):
                 ds.set_epoch(epoch)
             tr = self.train_epoch()
             va = self.validate()

@@ -110,6 +110,7 @@ enum FnetOpCode {
     FNET_OP_STENCIL = 28,
     FNET_OP_AFFINE_GRAD_MULTI = 29,
     FNET_OP_METRICS = 30,
+    FNET_OP_GATHER_BATCH = 31,
     FNET_OP_COUNT_
 };
 

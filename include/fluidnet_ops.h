@@ -103,6 +103,12 @@
  *   p: 0 pred [B,3,H,W], 1 target, 2 emitter, 3 collider, 4 sums double[16] (zero first): [0..2] squared error per
  *      channel, [3],[4] |d/dx|,|d/dy| of the density error, [5] divergence^2, [6] vx^2+vy^2, [7] collider cells,
  *      [8] density in collider, [9] emitter cells, [10] density in emitter, [11] SSIM map sum over the cropped interior
+ * GATHER_BATCH      <- FluidNPZSequenceDataset.__getitem__ + default collate + flip augmentation, from an HBM-resident
+ *                      sequence store (ml/dataset/npz_sequence.py:349-433, ml/dataset/augmentations.py:20-35)
+ *   i: 0 B, 1 H, 2 W, 3 K, 4 Km (mask frames, K or K+1), 5 mask_first (masks start at t + this), 6 Ttotal
+ *   p: 0 frames fp32 [5][Ttotal][H][W] (density, velx, velz, emitter, collider; all sequences back to back, already
+ *      normalised), 1 int32[B] global frame index of each sample's t, 2 int32[B] flip flags,
+ *      3 x0 out [B,6,H,W], 4 y_seq out [B,K,3,H,W], 5 masks out [B,Km,2,H,W]
  * COPY_PLANES       <- the autoregressive state hand-off (ml/scripts/simple_infer.py:259-260)
  *   i: 0 B, 1 count, 2 src batch stride, 3 dst batch stride (floats); p: 0 src, 1 dst
  * STENCIL           <- compute_spatial_gradients / compute_divergence (physics_loss.py:19-91)

@@ -105,3 +105,30 @@ def test_train_loop_checkpoint_and_backend(tmp_path):
     np.testing.assert_allclose(out, ref, atol=1e-6)
     tr.save_checkpoint(0)
     assert tr.load_checkpoint(tr.config.checkpoint_dir / "checkpoint_epoch_1.pth") == 0
+
+
+def test_hbm_loader_epoch_equals_dataloader_epoch(tmp_path):
+    """Trainer fed by the HBM-resident loader (one gather kernel per batch into the plan's buffers) takes the same steps as
+    Trainer fed the same samples as host batches."""
+    from fluidnet_amd.dataset.hbm_resident import HbmBatchLoader, HbmSequenceStore
+    root = _npz(tmp_path)
+    cfgT = _config(tmp_path, 2)
+    ds = FluidNPZSequenceDataset(root, "train", rollout_steps=2, preload=True, stride=1)
+    loader = HbmBatchLoader(HbmSequenceStore(ds), 2, shuffle=True, seed=3)
+    host_batches = []
+    for rows, _ in loader.batches():
+        samples = [ds[int(i)] for i in rows]
+        host_batches.append(tuple(torch.stack([s[j] for s in samples]) for j in range(3)))
+    out = {}
+    for name, feed in (("hbm", loader), ("host", host_batches)):
+        model, _ = _model()
+        tr = Trainer(model, feed, host_batches[:1], cfgT, "cuda", engine="plan")
+        d = tr.train_epoch()
+        out[name] = (d, model.flat_params.detach().cpu().clone())
+    assert len(host_batches) == len(loader) >= 2
+    for k in out["host"][0]:      # later steps see weights that differ by the rounding noise of the atomics-based backward
+        assert abs(out["hbm"][0][k] - out["host"][0][k]) <= 2e-4 * max(1.0, abs(out["host"][0][k])), k
+    # Adam turns a noise-level gradient element (rounding of the atomics-based backward) into a full +-lr step, so two correct
+    # runs can drift by lr per step in such elements; anything systematic (a wrong sample, flip or mask) moves every weight
+    diff = (out["hbm"][1] - out["host"][1]).abs()
+    assert diff.max() <= 1.05e-3 * len(loader) and float((diff > 1e-4).float().mean()) < 0.05

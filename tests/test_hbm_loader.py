@@ -1,0 +1,92 @@
+"""HBM-resident dataset: host-side batching logic on CPU (sharding, determinism, epoch offsets) and, on the GPU, the
+GATHER_BATCH kernel against FluidNPZSequenceDataset.__getitem__ (bit-exact: it only moves, mirrors and negates fp32 values)."""
+import numpy as np
+import pytest
+import torch
+
+from fluidnet_amd.dataset import FluidNPZSequenceDataset
+from fluidnet_amd.dataset.augmentations import apply_horizontal_flip
+from fluidnet_amd.dataset.hbm_resident import HbmBatchLoader, HbmSequenceStore
+
+
+@pytest.fixture()
+def npz_root(tmp_path):
+    rs = np.random.RandomState(3)
+    d = tmp_path / "npz" / "train"
+    d.mkdir(parents=True)
+    for i, T in enumerate((14, 9, 11)):
+        seq = {k: rs.randn(T, 12, 20).astype(np.float32) for k in ("density", "velx", "velz")}
+        seq["emitter"] = (rs.rand(T, 12, 20) > 0.9).astype(np.float32)
+        seq["collider"] = (rs.rand(T, 12, 20) > 0.9).astype(np.float32)
+        np.savez_compressed(d / f"seq_{i:04d}.npz", **seq)
+    (tmp_path / "_field_stats.yaml").write_text("normalization_scales:\n  S_density: 2.0\n  S_velx: 0.5\n  S_velz: 4.0\n")
+    return tmp_path / "npz"
+
+
+class _FakeStore:          # batches() only needs the dataset: lets the sharding logic run without a GPU
+    def __init__(self, ds):
+        self.dataset = ds
+        self.frames = torch.zeros(1)
+
+
+def test_batches_shard_disjointly_and_deterministically(npz_root):
+    ds = FluidNPZSequenceDataset(npz_root, "train", rollout_steps=2, stride=2, is_training=True,
+                                 augmentation_config={"enable_augmentation": True, "flip_probability": 0.5})
+    loaders = [HbmBatchLoader(_FakeStore(ds), 2, seed=5, rank=r, world=2) for r in range(2)]
+    for epoch in (0, 1):
+        for ld in loaders:
+            ld.set_epoch(epoch)
+        b0, b1 = loaders[0].batches(), loaders[1].batches()
+        assert len(b0) == len(b1) == len(ds) // 4 == len(loaders[0])
+        seen = np.concatenate([r for r, _ in b0] + [r for r, _ in b1])
+        assert len(set(seen.tolist())) == len(seen) and seen.max() < len(ds)          # no sample twice in an epoch, across ranks
+        again = loaders[0].batches()
+        assert all((a[0] == b[0]).all() and (a[1] == b[1]).all() for a, b in zip(b0, again))
+    loaders[0].set_epoch(0); e0 = loaders[0].batches()
+    loaders[0].set_epoch(2); e2 = loaders[0].batches()
+    assert any((a[0] != b[0]).any() for a, b in zip(e0, e2))                          # reshuffled per epoch
+    flips = np.concatenate([f for _, f in e0])
+    assert set(flips.tolist()) <= {0, 1}
+    noaug = HbmBatchLoader(_FakeStore(FluidNPZSequenceDataset(npz_root, "train", rollout_steps=2)), 2)
+    assert all(f.sum() == 0 for _, f in noaug.batches())
+    with pytest.raises(ValueError):
+        HbmBatchLoader(_FakeStore(ds), 2, mask_frames=5)
+
+
+def test_store_requires_gpu(npz_root):
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        HbmSequenceStore(FluidNPZSequenceDataset(npz_root, "train"), device="cpu")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,normalize,preload", [(1, False, True), (3, True, True), (3, True, False)])
+def test_gather_matches_dataset_getitem(npz_root, K, normalize, preload):
+    ds = FluidNPZSequenceDataset(npz_root, "train", normalize=normalize, preload=preload, rollout_steps=K, stride=2)
+    store = HbmSequenceStore(ds)
+    Km = K if (preload or K == 1) else K + 1                  # the reference's two mask conventions (preloaded / on-disk)
+    ld = HbmBatchLoader(store, 4, shuffle=True, seed=1, mask_frames=Km)
+    for epoch in (0, 1):
+        ld.set_epoch(epoch)
+        for rows, _ in ld.batches():
+            flips = np.array([0, 1, 0, 1], dtype=np.int32)
+            x0 = torch.empty(4, 6, 12, 20, device="cuda")
+            y = torch.empty(4, K, 3, 12, 20, device="cuda")
+            mk = torch.empty(4, Km, 2, 12, 20, device="cuda")
+            ld.gather(rows, flips, x0, y, mk)
+            for j, i in enumerate(rows):
+                s = ds[int(i)]
+                if K == 1:
+                    ex, ey = s
+                    if flips[j]:
+                        ex, ey = apply_horizontal_flip(ex, ey)
+                    assert torch.equal(x0[j].cpu(), ex) and torch.equal(y[j, 0].cpu(), ey)
+                else:
+                    ex, ey, em = s
+                    if flips[j]:
+                        ex, ey, em = torch.flip(ex, dims=[2]), torch.flip(ey, dims=[3]), torch.flip(em, dims=[3])
+                        ex[1] = -ex[1]
+                        ey[:, 1] = -ey[:, 1]
+                    assert torch.equal(x0[j].cpu(), ex) and torch.equal(y[j].cpu(), ey) and torch.equal(mk[j].cpu(), em)
+    # DataLoader-style iteration yields the dataset's tuple shapes
+    b = next(iter(ld))
+    assert len(b) == (2 if K == 1 else 3) and b[0].shape == (4, 6, 12, 20)

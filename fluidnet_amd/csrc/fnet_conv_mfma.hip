@@ -681,6 +681,12 @@ int fnet_conv3x3_mfma(const FnetOp& op, hipStream_t st) {
         const long long items_b = (long long)((Npix + 511) / 512) * ((Cout + tn_b - 1) / tn_b);
         big = items_b >= 3ll * cus;
         if (forced) big = forced == 2;
+        // wide images: the big tile's two stage buffers (input run of 512 + 2Wp + 2 pixels) must fit the CU's 160 KB of LDS
+        const size_t rin_b = (size_t)(512 + 2 * Wp + 2 + 31) / 32 * 32;
+        size_t buf_b = rin_b * 32 + (size_t)9 * tn_b * 32;
+        const size_t out_b = (size_t)512 * 64 * 2 + 2048;
+        if (buf_b < out_b) buf_b = out_b;
+        if (2 * buf_b > 160 * 1024) big = false;
     }
     const int tm = big ? 512 : TM;
     const int TN = big ? (Cout > 64 ? 128 : 64) : (Cout > 32 ? 64 : 32);

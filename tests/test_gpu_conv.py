@@ -23,6 +23,7 @@ SHAPES = [
     (2, 16, 16, 256, 64, 256, 0, 64, 0),
     (2, 30, 34, 48, 24, 48, 0, 24, 0),
     (1, 8, 8, 128, 256, 256, 128, 256, 0),
+    (1, 6, 520, 32, 128, 32, 0, 128, 0),       # wide image: the 512-pixel tile's stage buffers would not fit LDS -> small-tile fallback
 ]
 
 

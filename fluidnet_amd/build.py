@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libfluidnet_hip.so")
-SOURCES = ["fnet_elementwise.hip", "fnet_loss.hip", "fnet_conv_ref.hip", "fnet_conv_mfma.hip", "fnet_optim.hip", "fnet_plan.hip"]
+SOURCES = ["fnet_elementwise.hip", "fnet_loss.hip", "fnet_conv_ref.hip", "fnet_conv_mfma.hip", "fnet_optim.hip", "fnet_plan.hip", "fnet_rollout.hip"]
 HEADERS = [os.path.join(CSRC, "fnet_common.h"), os.path.join(os.path.dirname(HERE), "include", "fluidnet_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-Wall", "-Wno-unused-function", "-Wno-unused-value"]
 

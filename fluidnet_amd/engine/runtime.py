@@ -77,6 +77,16 @@ def lib() -> ctypes.CDLL:
     L.fnet_timer_elapsed_ms.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]
     L.fnet_timer_destroy.restype = ctypes.c_int
     L.fnet_timer_destroy.argtypes = [ctypes.c_void_p]
+    i32, i64, vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p
+    fpp = ctypes.POINTER(ctypes.c_void_p)
+    sigs = {"fnet_unet_param_count": [vp, ctypes.POINTER(i64)],
+            "fnet_rollout_create": [vp, vp, i64, i32, i32, i32, fpp],
+            "fnet_rollout_set_weights": [vp, vp, i64], "fnet_rollout_set_masks": [vp, vp, vp], "fnet_rollout_set_state": [vp, vp, vp],
+            "fnet_rollout_add_impulse": [vp, vp, vp], "fnet_rollout_step": [vp, i32, vp], "fnet_rollout_state_ptr": [vp, fpp, fpp],
+            "fnet_rollout_read_state": [vp, vp, vp], "fnet_rollout_destroy": [vp]}
+    for name, args in sigs.items():
+        getattr(L, name).restype = ctypes.c_int
+        getattr(L, name).argtypes = args
     if L.fnet_abi_version() != 1:
         raise FluidNetHipError("libfluidnet_hip.so ABI version mismatch; rebuild with `python -m fluidnet_amd.build --force`")
     _lib = L
@@ -85,7 +95,9 @@ def lib() -> ctypes.CDLL:
 
 EXPORTS = ["fnet_abi_version", "fnet_strerror", "fnet_last_hip_error", "fnet_device_info", "fnet_plan_run", "fnet_graph_create",
            "fnet_graph_launch", "fnet_graph_destroy", "fnet_spatial_gradients", "fnet_divergence", "fnet_timer_create",
-           "fnet_timer_start", "fnet_timer_stop", "fnet_timer_elapsed_ms", "fnet_timer_destroy"]
+           "fnet_timer_start", "fnet_timer_stop", "fnet_timer_elapsed_ms", "fnet_timer_destroy", "fnet_unet_param_count",
+           "fnet_rollout_create", "fnet_rollout_set_weights", "fnet_rollout_set_masks", "fnet_rollout_set_state", "fnet_rollout_add_impulse",
+           "fnet_rollout_step", "fnet_rollout_state_ptr", "fnet_rollout_read_state", "fnet_rollout_destroy"]
 
 
 def check(rc: int, what: str = "", ops: Optional[np.ndarray] = None, failed: int = -1) -> None:

@@ -166,6 +166,45 @@ int fnet_timer_stop(void* timer, void* stream);
 int fnet_timer_elapsed_ms(void* timer, float* ms_out);
 int fnet_timer_destroy(void* timer);
 
+/*
+ * Native inference rollout: the per-step work of the reference's C++ viewer
+ * (engine/src/Simulation.cpp:236-367: pack six planes, Ort::Session::Run, copy the output into
+ * the back buffer) as one device-resident loop.  Model family: norm = instance, downsample =
+ * stride (UNet_medium's); weights = the trainable tensors of a reference checkpoint in
+ * state-dict order (ml/models/unet.py:204-279), concatenated as fp32; bf16 MFMA arithmetic.
+ *   fnet_unet_param_count   number of floats fnet_rollout_create expects for a configuration
+ *   fnet_rollout_create     allocates every device buffer (hipMalloc), uploads and re-lays the weights,
+ *                           captures one frame in a hipGraph; synchronises
+ *   fnet_rollout_set_weights / set_masks / set_state   host -> device uploads (null = zeros); synchronise
+ *   fnet_rollout_add_impulse  velx += ix, vely += iy from a host [B][2][H][W] array (Simulation.cpp:263-271); async on `stream`
+ *   fnet_rollout_step       `frames` graph replays on `stream`: state_prev <- density, state <- UNet(state, prev, masks)
+ *   fnet_rollout_state_ptr  device pointers of the state [B][3][H][W] and the previous density [B][H][W]
+ *   fnet_rollout_read_state device -> host copy of the state; synchronises `stream`
+ */
+typedef struct FnetUNetConfig {
+    int32_t in_channels;        /* 6 */
+    int32_t out_channels;       /* 3 */
+    int32_t base_channels;      /* multiple of 8, <= 64 */
+    int32_t depth;
+    int32_t act;                /* FNET_ACT_* */
+    int32_t padding_mode;       /* FNET_PAD_* */
+    int32_t upsample;           /* 0 nearest, 1 bilinear */
+    int32_t use_residual;       /* 0 / 1 */
+    int32_t bottleneck_blocks;
+    int32_t output_activation;  /* FNET_OUT_* */
+} FnetUNetConfig;
+int fnet_unet_param_count(const FnetUNetConfig* cfg, int64_t* n_floats);
+int fnet_rollout_create(const FnetUNetConfig* cfg, const float* host_params, int64_t n_params, int32_t B, int32_t H, int32_t W,
+                        void** handle_out);
+int fnet_rollout_set_weights(void* handle, const float* host_params, int64_t n_params);
+int fnet_rollout_set_masks(void* handle, const float* host_emitter, const float* host_collider);
+int fnet_rollout_set_state(void* handle, const float* host_state, const float* host_prev_density);
+int fnet_rollout_add_impulse(void* handle, const float* host_impulse_xy, void* stream);
+int fnet_rollout_step(void* handle, int32_t frames, void* stream);
+int fnet_rollout_state_ptr(void* handle, float** device_state, float** device_prev_density);
+int fnet_rollout_read_state(void* handle, float* host_state, void* stream);
+int fnet_rollout_destroy(void* handle);
+
 #ifdef __cplusplus
 }
 #endif

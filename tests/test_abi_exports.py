@@ -5,6 +5,7 @@ import os
 import re
 import subprocess
 
+import numpy as np
 import pytest
 
 from fluidnet_amd.engine import runtime as rt
@@ -62,3 +63,22 @@ def test_plan_run_rejects_bad_record_without_a_gpu():
     failed = ctypes.c_int32(-1)
     rc = rt.lib().fnet_plan_run(ops.ctypes.data, 2, None, ctypes.byref(failed))
     assert rc in (-1, -3) and failed.value == 1
+
+
+def test_native_param_count_matches_the_state_dict(tmp_path):
+    """fnet_unet_param_count (host-only, no GPU) from a plain C program linked against the library: the native rollout's
+    parameter table must describe exactly the reference state dict (6,031,491 floats for UNet_medium)."""
+    import fluidnet_oracle as orc
+    want = sum(int(np.prod(s)) for s in orc.param_shapes(orc.medium_config()).values())
+    src = tmp_path / "pc.c"
+    src.write_text('#include <stdio.h>\n#include "fluidnet_hip.h"\n'
+                   'int main(void){FnetUNetConfig c={6,3,32,3,FNET_ACT_GELU,FNET_PAD_REPLICATE,1,1,1,FNET_OUT_LINEAR_CLAMP};'
+                   'int64_t n=0; int rc=fnet_unet_param_count(&c,&n); printf("%d %lld\\n", rc, (long long)n);'
+                   'c.depth=0; rc=fnet_unet_param_count(&c,&n); printf("%d\\n", rc); return 0;}\n')
+    exe = tmp_path / "pc.bin"
+    libdir = os.path.dirname(rt.LIB_PATH)
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe), "-L", libdir, "-lfluidnet_hip",
+                           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.check_output([str(exe)]).split()
+    assert int(out[0]) == 0 and int(out[1]) == want
+    assert int(out[2]) == -1                       # FNET_E_BADARG for an unsupported configuration

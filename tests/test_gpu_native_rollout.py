@@ -1,0 +1,73 @@
+"""Native rollout C ABI (fnet_rollout_*, no torch on its path) against the Python-built RolloutInferPlan on the same weights:
+both hosts emit the same op records, so the states must agree bit for bit; plus the viewer's impulse contract and argument
+checking.  The Python plan itself is checked against the oracle in tests/test_gpu_api.py / test_gpu_lockstep.py."""
+import numpy as np
+import pytest
+import torch
+
+import fluidnet_oracle as orc
+from fluidnet_amd.engine.native_rollout import NativeRollout
+from fluidnet_amd.engine.rollout_plan import RolloutInferPlan
+from fluidnet_amd.engine.runtime import FluidNetHipError
+from fluidnet_amd.models.unet import UNet, UNetConfig
+from helpers import tiny_cfg
+
+pytestmark = pytest.mark.gpu
+
+
+def _weights(cfg, seed):
+    params = orc.make_params(cfg, seed=seed)
+    return params, np.concatenate([v.reshape(-1).numpy() for v in params.values()]).astype(np.float32)
+
+
+@pytest.mark.parametrize("name,cfg,B,R", [
+    ("tiny", tiny_cfg(), 2, 32),
+    ("tiny-noresid-nearest-zeros", tiny_cfg(use_residual=False, upsample="nearest", padding_mode="zeros", act="silu"), 1, 16),
+    ("medium", orc.medium_config(dropout=0.0), 3, 64),
+])
+def test_native_rollout_equals_python_plan(name, cfg, B, R):
+    params, flat = _weights(cfg, seed=3)
+    model = UNet(UNetConfig(**cfg.__dict__), precision="bf16")
+    model.load_state_dict(params)
+    model = model.cuda().eval()
+    em, co = orc.simple_infer_masks(R, scale=R / 128.0)
+    e = np.repeat(em[None], B, 0).astype(np.float32)
+    c = np.repeat(co[None], B, 0).astype(np.float32)
+    plan = RolloutInferPlan(model.cfg, B, R, R, params_flat=model.flat_params)
+    plan.reset(torch.from_numpy(e).cuda(), torch.from_numpy(c).cuda())
+    nat = NativeRollout(model.cfg, flat, B, R, R)
+    nat.set_masks(e, c)
+    nat.set_state(None, None)
+    for frames in (1, 4):
+        want = plan.step(frames).cpu().numpy()
+        nat.step(frames)
+        got = nat.read_state()
+        assert np.isfinite(got).all()
+        assert np.array_equal(got, want), (name, frames, float(np.abs(got - want).max()))
+    # impulse: velx += ix, vely += iy on the current state (Simulation.cpp:263-271)
+    rs = np.random.RandomState(0)
+    imp = (0.1 * rs.randn(B, 2, R, R)).astype(np.float32)
+    before = nat.read_state()
+    nat.add_impulse(imp)
+    after = nat.read_state()
+    assert np.array_equal(after[:, 0], before[:, 0]) and np.allclose(after[:, 1:], before[:, 1:] + imp, atol=1e-7)
+    plan.cur.tensor[:, 1:] += torch.from_numpy(imp).cuda()
+    nat.step(1)
+    assert np.array_equal(nat.read_state(), plan.step(1).cpu().numpy())
+    nat.close()
+
+
+def test_native_rollout_rejects_bad_arguments():
+    cfg = tiny_cfg()
+    _, flat = _weights(cfg, seed=1)
+    mcfg = UNetConfig(**cfg.__dict__)
+    with pytest.raises(ValueError):
+        NativeRollout(mcfg, flat[:-1], 1, 32, 32)
+    with pytest.raises(FluidNetHipError):
+        NativeRollout(mcfg, flat, 1, 30, 32)            # not divisible by 2^depth
+    with pytest.raises(NotImplementedError):
+        NativeRollout(UNetConfig(**tiny_cfg(norm="batch").__dict__), flat, 1, 32, 32)
+    nat = NativeRollout(mcfg, flat, 1, 32, 32)
+    with pytest.raises(ValueError):
+        nat.set_masks(np.zeros((2, 32, 32), np.float32), None)
+    nat.close()

@@ -30,6 +30,17 @@ class AugmentationConfig(BaseModel):
     flip_axis: str = "x"
 
 
+class VariantMetadata(BaseModel):
+    """ml/config/training_config.py:30-37"""
+    variant_name: str
+    model_architecture_name: str
+    full_model_name: str
+    parent_variant: Optional[str] = None
+    warmstart_checkpoint: Optional[Path] = None
+    variant_yaml_path: Path
+    relative_dir: Path
+
+
 class TrainingConfig(BaseModel):
     batch_size: int = 4
     learning_rate: float = 0.0007
@@ -83,7 +94,7 @@ class TrainingConfig(BaseModel):
     early_stop_min_delta: float = 0
 
     physics_loss: PhysicsLossConfig = PhysicsLossConfig()
-    variant: Optional[dict] = None
+    variant: Optional[VariantMetadata] = None
 
     rollout_step: int = 0
     rollout_stride: float = 1.0
@@ -91,6 +102,13 @@ class TrainingConfig(BaseModel):
     rollout_gradient_truncation: bool = False
     validation_use_rollout_k: bool = True
     rollout_final_step_only: bool = False
+
+    @property
+    def checkpoint_dir_variant(self) -> Path:
+        """ml/config/training_config.py:131-135"""
+        if self.variant:
+            return self.checkpoint_dir / self.variant.relative_dir / self.variant.full_model_name
+        return self.checkpoint_dir / "Unet"
 
     @field_validator("rollout_step")
     @classmethod

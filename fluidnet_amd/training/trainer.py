@@ -89,7 +89,10 @@ class Trainer:
         self.optimizer = FusedClipAdam(model, config.learning_rate, config.gradient_clip_norm if config.gradient_clip_enabled else None)
         self.scaler = None                                   # bf16 storage / fp32 accumulate needs no loss scaling
         self.scheduler = _Scheduler(self.optimizer, config) if config.use_lr_scheduler else None
-        ckdir = Path(config.checkpoint_dir) / str(getattr(model, "model_name", "Unet"))
+        if getattr(config, "variant", None):                 # curriculum runs: <checkpoints>/<relative dir>/<arch>_<variant> (trainer.py:71-74)
+            ckdir = Path(config.checkpoint_dir_variant)
+        else:
+            ckdir = Path(config.checkpoint_dir) / str(getattr(model, "model_name", "Unet"))
         self.early_stopping = EarlyStopping(config.early_stop_patience, config.early_stop_min_delta, ckdir) if config.use_early_stopping else None
         self.config.checkpoint_dir = ckdir
         ckdir.mkdir(parents=True, exist_ok=True)

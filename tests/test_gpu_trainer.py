@@ -132,3 +132,37 @@ def test_hbm_loader_epoch_equals_dataloader_epoch(tmp_path):
     # runs can drift by lr per step in such elements; anything systematic (a wrong sample, flip or mask) moves every weight
     diff = (out["hbm"][1] - out["host"][1]).abs()
     assert diff.max() <= 1.05e-3 * len(loader) and float((diff > 1e-4).float().mean()) < 0.05
+
+
+def test_curriculum_k1_then_k2_with_warm_start(tmp_path):
+    """Two curriculum stages from YAML variants (ml/scripts/train.py flow): K1 trains from scratch, K2 warm-starts from K1's
+    best_model.pth, both through the native plan engine; the second stage also exercises the HBM-resident loader."""
+    import yaml
+    from fluidnet_amd.training.curriculum import train_curriculum
+    from fluidnet_amd.training.variants import VariantManager
+    root = _npz(tmp_path)
+    cfg_root = tmp_path / "config"
+    (cfg_root / "model_architectures").mkdir(parents=True)
+    (cfg_root / "variants" / "t").mkdir(parents=True)
+    (cfg_root / "base_config.yaml").write_text(yaml.safe_dump({
+        "batch_size": 2, "epochs": 1, "normalize": False, "preload_dataset": True, "use_lr_scheduler": False, "use_early_stopping": True,
+        "learning_rate": 1e-3, "augmentation": {"enable_augmentation": True, "flip_probability": 0.5},
+        "physics_loss": {"enable_divergence": True, "enable_gradient": True, "enable_emitter": True, "grid_spacing": 2.0 / 32}}))
+    (cfg_root / "model_architectures" / "Tiny.yaml").write_text(yaml.safe_dump({
+        "base_channels": 8, "depth": 2, "norm": "instance", "act": "gelu", "dropout": 0.0, "upsample": "bilinear", "downsample": "stride",
+        "padding_mode": "replicate", "use_residual": True, "bottleneck_blocks": 1}))
+    (cfg_root / "variants" / "t" / "K1.yaml").write_text(yaml.safe_dump({"variant_name": "K1", "model_architecture": "Tiny", "rollout_step": 1}))
+    (cfg_root / "variants" / "t" / "K2.yaml").write_text(yaml.safe_dump({"variant_name": "K2", "parent_variant": "K1", "rollout_step": 2}))
+    m = VariantManager(cfg_root, tmp_path / "ck")
+    out = train_curriculum(m, ["K1"], root)
+    k1_best = tmp_path / "ck" / "t" / "Tiny_K1" / "best_model.pth"
+    assert list(out) == ["K1"] and k1_best.exists()
+    out = train_curriculum(m, ["K2"], root, use_hbm_loader=True)
+    assert list(out) == ["K2"]                                   # K1 has a checkpoint: not retrained
+    tr = out["K2"]
+    assert tr.config.variant.warmstart_checkpoint == k1_best and (tmp_path / "ck" / "t" / "Tiny_K2" / "best_model.pth").exists()
+    assert np.isfinite(tr.history["val_total"][0]) and "ssim_density" not in tr.history
+    # the warm start really loaded K1's weights: K2's first-epoch weights stay close to them (1 epoch at lr 1e-3)
+    k1 = torch.load(k1_best, weights_only=True)["model_state_dict"]
+    k2 = torch.load(tmp_path / "ck" / "t" / "Tiny_K2" / "best_model.pth", weights_only=True)["model_state_dict"]
+    assert max(float((k1[k] - k2[k]).abs().max()) for k in k1) < 0.05

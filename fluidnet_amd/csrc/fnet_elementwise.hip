@@ -405,7 +405,7 @@ __global__ __launch_bounds__(256) void k_inact_bwd_reduce(const T* __restrict__ 
         }
         const size_t img = (size_t)n * Hp * Wp;
         const T* rbase = raw + img * ldc_raw + coff_raw + c0;
-        T* Gbase = G + img * ldc_G + coff_G + c0;
+        T* Gbase = G ? G + img * ldc_G + coff_G + c0 : nullptr;    // G == 0: single-source unit, pass 2 re-reads (and re-folds) g1
         const T* g1img = g1 + img * ldc_g1 + coff_g1 + c0;
         const T* g2img = g2 ? g2 + img * ldc_g2 + coff_g2 + c0 : nullptr;
         const bool f1 = fold1 && pm != FNET_PAD_ZEROS, f2 = fold2 && pm != FNET_PAD_ZEROS;
@@ -448,7 +448,7 @@ __global__ __launch_bounds__(256) void k_inact_bwd_reduce(const T* __restrict__ 
                 Vec8<T> go;
 #pragma unroll
                 for (int k = 0; k < 8; ++k) go.v[k] = acc[k];
-                go.store_nt(Gbase + pix[u] * ldc_G);
+                if (Gbase) go.store_nt(Gbase + pix[u] * ldc_G);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     // use the value as stored (bf16-rounded in bf16 mode) so that pass 2 sees the same G
@@ -492,7 +492,7 @@ template <typename T, int ACT>
 __global__ __launch_bounds__(256) void k_inact_bwd_apply(const T* __restrict__ G, const T* __restrict__ raw, const float2* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta,
                                   const float2* __restrict__ S, T* __restrict__ draw, int H, int W, int C, int ldc_G, int coff_G, int ldc_raw,
                                   int coff_raw, int ldc_d, int coff_d, int act, uint32_t site, uint32_t seed, float drop_p,
-                                  int p_per_block) {
+                                  int p_per_block, int fold, int pm) {
     const CgMap m(C);
     if (!m.active) return;
     const int n = blockIdx.y, Hp = H + 2, Wp = W + 2, c0 = m.cg * 8;
@@ -516,13 +516,19 @@ __global__ __launch_bounds__(256) void k_inact_bwd_apply(const T* __restrict__ G
     const T* rbase = raw + img * ldc_raw + coff_raw + c0;
     T* dbase = draw + img * ldc_d + coff_d + c0;
     PixWalk w(p, ps, Wp);
+    // fold != 0: `G` is the unit's single gradient source itself (pass 1 wrote no G): ring copies are folded onto the pixels they
+    // copy here, exactly as pass 1 did (same order, same rounding), so both forms give the same bits
+    const bool do_fold = fold && pm != FNET_PAD_ZEROS;
+    const int fylo = pad_lo(H, pm), fyhi = pad_hi(H, pm), fxlo = pad_lo(W, pm), fxhi = pad_hi(W, pm);
     auto trip = [&](auto uc) {
         constexpr int UU = decltype(uc)::value;
         Vec8<T> g[UU], r[UU];
         uint32_t keep[UU];
+        int yy[UU], xx[UU];
 #pragma unroll
         for (int u = 0; u < UU; ++u) {
             keep[u] = (w.y == 0 || w.y == Hp - 1 || w.x == 0 || w.x == Wp - 1) ? 0u : 0xffffffffu;   // ring: loaded all the same (valid memory), zeroed below
+            yy[u] = w.y - 1; xx[u] = w.x - 1;
             const size_t pu = (size_t)(p + u * ps);
             g[u].load(Gbase + pu * ldc_G);
             r[u].load(rbase + pu * ldc_raw);
@@ -530,6 +536,13 @@ __global__ __launch_bounds__(256) void k_inact_bwd_apply(const T* __restrict__ G
         }
 #pragma unroll
         for (int u = 0; u < UU; ++u) {
+            if (do_fold && keep[u] && (yy[u] == fylo || yy[u] == fyhi || xx[u] == fxlo || xx[u] == fxhi)) {
+                fold_extras8<T>(Gbase, yy[u], xx[u], H, W, ldc_G, pm, g[u].v);
+                if (sizeof(T) == 2) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) g[u].v[k] = bf2f(f2bf(g[u].v[k]));
+                }
+            }
             Vec8<T> o;
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
@@ -929,7 +942,8 @@ int fnet_op_inact_bwd_reduce(const FnetOp& op, hipStream_t st) {
     FNET_CHECK_ARG(vec_ok((void*)op.p[0], op.i[4], op.i[5], C, op.dtype));
     FNET_CHECK_ARG(vec_ok_opt((void*)op.p[1], op.i[6], op.i[7], C, op.dtype));
     FNET_CHECK_ARG(vec_ok((void*)op.p[2], op.i[8], op.i[9], C, op.dtype));
-    FNET_CHECK_ARG(vec_ok((void*)op.p[6], op.i[10], op.i[11], C, op.dtype));
+    FNET_CHECK_ARG(vec_ok_opt((void*)op.p[6], op.i[10], op.i[11], C, op.dtype));
+    FNET_CHECK_ARG(op.p[6] != 0 || op.p[1] == 0);          // G may be omitted only for a single gradient source
     FNET_CHECK_ARG(op.p[3] && op.p[4] && op.p[5] && op.p[7] && cg_ok(C, B) && ((op.p[8] == 0) == (op.p[9] == 0)));
     int chunks;
     const int per = cg_pixels_per_block(H * W, B, C, &chunks, 768);
@@ -943,7 +957,8 @@ int fnet_op_inact_bwd_reduce(const FnetOp& op, hipStream_t st) {
     return FNET_OK;
 }
 
-// INACT_BWD_APPLY  i: 0 B,1 H,2 W,3 C,4 ldc_G,5 coff_G,6 ldc_raw,7 coff_raw,8 ldc_d,9 coff_d,10 act,11 drop site,12 seed
+// INACT_BWD_APPLY  i: 0 B,1 H,2 W,3 C,4 ldc_G,5 coff_G,6 ldc_raw,7 coff_raw,8 ldc_d,9 coff_d,10 act,11 drop site,12 seed,
+//                     13 fold (p[0] is the unit's single gradient source, ring not yet folded),14 pm
 //                  f: 0 drop_p; p: 0 G,1 raw,2 stats,3 gamma,4 beta,5 S,6 d_raw out
 int fnet_op_inact_bwd_apply(const FnetOp& op, hipStream_t st) {
     const int B = op.i[0], H = op.i[1], W = op.i[2], C = op.i[3];
@@ -952,13 +967,14 @@ int fnet_op_inact_bwd_apply(const FnetOp& op, hipStream_t st) {
     FNET_CHECK_ARG(vec_ok((void*)op.p[1], op.i[6], op.i[7], C, op.dtype));
     FNET_CHECK_ARG(vec_ok((void*)op.p[6], op.i[8], op.i[9], C, op.dtype));
     FNET_CHECK_ARG(op.p[2] && op.p[3] && op.p[4] && op.p[5] && cg_ok(C, B));
+    FNET_CHECK_ARG((op.i[13] == 0 || op.i[13] == 1) && op.i[14] >= 0 && op.i[14] <= 3);
     int chunks;
     const int per = cg_pixels_per_block((H + 2) * (W + 2), B, C, &chunks, 768);
     DISPATCH_ACT(op.i[10], DISPATCH_T(op.dtype, hipLaunchKernelGGL((k_inact_bwd_apply<T, ACT>), dim3(chunks, B), dim3(kThreads), 0,
                                             st, (const T*)op.p[0], (const T*)op.p[1], (const float2*)op.p[2],
                                             (const float*)op.p[3], (const float*)op.p[4], (const float2*)op.p[5],
                                             (T*)op.p[6], H, W, C, op.i[4], op.i[5], op.i[6], op.i[7], op.i[8], op.i[9],
-                                            op.i[10], (uint32_t)op.i[11], (uint32_t)op.i[12], op.f[0], per)));
+                                            op.i[10], (uint32_t)op.i[11], (uint32_t)op.i[12], op.f[0], per, op.i[13], op.i[14])));
     FNET_LAUNCH_CHECK();
     return FNET_OK;
 }

@@ -448,27 +448,37 @@ class PlanBuilder:
         return t
 
     # -------------------------------------------------------------------------------------------- backward
-    def _unit_bwd(self, ops, u: Unit, srcs: List[GradSrc], need_dx: bool = True) -> Tuple[Optional[GradSrc], Buf]:
+    def _unit_bwd(self, ops, u: Unit, srcs: List[GradSrc], need_dx: bool = True, need_G: bool = False) -> Tuple[Optional[GradSrc], Optional[Buf]]:
         """Backward of one unit.  Consumes (releases) the temporaries behind `srcs`.  Returns (gradient wrt the unit's
-        input as a folded source or None, the materialised total gradient G wrt the unit's output (caller releases))."""
+        input as a folded source or None, the materialised total gradient G wrt the unit's output or None (caller releases)).
+        G is materialised when the caller needs it (need_G: it is also the gradient of a residual branch) or when there are two
+        gradient sources to add."""
         assert 1 <= len(srcs) <= 2
         B, H, W, C = self.B, u.out.H, u.out.W, u.out.C
-        G = self.tmp(H, W, C)
         S = self.s_alloc(B * C * 2)         # float2[B][C] in the S slab (zeroed once per backward pass: emit_backward)
         g1 = srcs[0]
         g2 = srcs[1] if len(srcs) > 1 else None
+        # One gradient source: pass 1 writes no G (a third of its traffic); pass 2 reads the source itself and folds its ring the
+        # same way.  Two sources: their folded sum is materialised once as G.
+        if os.environ.get("FNET_KEEP_G", "0") == "1":     # A/B switch: always materialise G (the two-source form everywhere)
+            need_G = True
+        G = self.tmp(H, W, C) if (g2 is not None or need_G) else None
         self.op(ops, "INACT_BWD_REDUCE",
                 [B, H, W, C, g1.pv.ldc, g1.pv.coff, g2.pv.ldc if g2 else 8, g2.pv.coff if g2 else 0, C, 0, C, 0,
                  g1.fold, g2.fold if g2 else 0, self.act, self.pm, u.drop_site, self.seed],
                 f=[u.drop_p],
                 p=[g1.pv.ref, g2.pv.ref if g2 else None, Ref(u.raw), Ref(u.st), self.pref(u.norm + ".weight"),
-                   self.pref(u.norm + ".bias"), Ref(G), S], tag=u.conv)
-        for s in srcs:
-            self.release(s.pv.buf)
+                   self.pref(u.norm + ".bias"), Ref(G) if G is not None else None, S], tag=u.conv)
         draw = self.tmp(H, W, C)
-        self.op(ops, "INACT_BWD_APPLY", [B, H, W, C, C, 0, C, 0, C, 0, self.act, u.drop_site, self.seed], f=[u.drop_p],
-                p=[Ref(G), Ref(u.raw), Ref(u.st), self.pref(u.norm + ".weight"), self.pref(u.norm + ".bias"), S, Ref(draw)],
+        if G is not None:
+            gp, gl, gc, gf = Ref(G), C, 0, 0
+        else:
+            gp, gl, gc, gf = g1.pv.ref, g1.pv.ldc, g1.pv.coff, g1.fold
+        self.op(ops, "INACT_BWD_APPLY", [B, H, W, C, gl, gc, C, 0, C, 0, self.act, u.drop_site, self.seed, gf, self.pm], f=[u.drop_p],
+                p=[gp, Ref(u.raw), Ref(u.st), self.pref(u.norm + ".weight"), self.pref(u.norm + ".bias"), S, Ref(draw)],
                 tag=u.conv)
+        for s in srcs:                      # only now: in the single-source form pass 2 still reads srcs[0]
+            self.release(s.pv.buf)
         # dgamma/dbeta: a separate tiny kernel (adding them from every block of the reduce kernel, hundreds of adders per
         # address, cost more), batched over the layers of the backward pass by emit_backward (flush_affine)
         self._affine_pending.append((S, C, self.gref(u.norm + ".weight"), self.gref(u.norm + ".bias"), u.norm))
@@ -485,11 +495,12 @@ class PlanBuilder:
     def _block_bwd(self, ops, units: List[Unit], srcs: List[GradSrc], residual: bool, need_dx: bool = True) -> List[GradSrc]:
         """Backward of a ConvBlock (residual=False) or ResBlock y = x + B(x) (residual=True); returns sources for x."""
         u1, u2 = units
-        g_a1, Gy = self._unit_bwd(ops, u2, srcs)
-        if not residual:
+        g_a1, Gy = self._unit_bwd(ops, u2, srcs, need_G=residual)
+        if not residual and Gy is not None:
             self.release(Gy)
         g_x, G1 = self._unit_bwd(ops, u1, [g_a1], need_dx=need_dx)
-        self.release(G1)
+        if G1 is not None:
+            self.release(G1)
         out = []
         if g_x is not None:
             out.append(g_x)

@@ -68,11 +68,13 @@
  *   i: 0 B, 1 H, 2 W, 3 C, 4 ldc_g1, 5 coff_g1, 6 ldc_g2, 7 coff_g2, 8 ldc_raw, 9 coff_raw, 10 ldc_G, 11 coff_G,
  *      12 fold1, 13 fold2 (1 = the gradient's ring is folded onto the interior per pm), 14 act, 15 pm,
  *      16 dropout site, 17 seed; f: 0 drop_p
- *   p: 0 g1 P, 1 g2 P|0, 2 raw P, 3 stats, 4 gamma, 5 beta, 6 G out P, 7 S float2[B][C] (+=; zero first),
- *      8 dgamma|0 (+=), 9 dbeta|0 (+=) (both or neither)
+ *   p: 0 g1 P, 1 g2 P|0, 2 raw P, 3 stats, 4 gamma, 5 beta, 6 G out P|0 (0 only with one source: pass 2 then reads g1
+ *      itself), 7 S float2[B][C] (+=; zero first), 8 dgamma|0 (+=), 9 dbeta|0 (+=) (both or neither)
  * INACT_BWD_APPLY   <- pass 2: gradient w.r.t. the conv output
- *   i: 0 B, 1 H, 2 W, 3 C, 4 ldc_G, 5 coff_G, 6 ldc_raw, 7 coff_raw, 8 ldc_d, 9 coff_d, 10 act, 11 dropout site, 12 seed
- *   f: 0 drop_p; p: 0 G, 1 raw, 2 stats, 3 gamma, 4 beta, 5 S, 6 d_raw out P (ring = 0)
+ *   i: 0 B, 1 H, 2 W, 3 C, 4 ldc_G, 5 coff_G, 6 ldc_raw, 7 coff_raw, 8 ldc_d, 9 coff_d, 10 act, 11 dropout site, 12 seed,
+ *      13 fold (1 = p[0] is an unfolded gradient source: its ring is folded onto the interior here, rounded to the
+ *      element type exactly as pass 1 would have stored it in G), 14 pm (used when fold = 1)
+ *   f: 0 drop_p; p: 0 G (or the single source g1), 1 raw, 2 stats, 3 gamma, 4 beta, 5 S, 6 d_raw out P (ring = 0)
  * AFFINE_GRAD       i: 0 B, 1 C; p: 0 S float2[B][C], 1 dgamma (+=), 2 dbeta (+=)
  * AFFINE_GRAD_MULTI AFFINE_GRAD of up to 7 norm layers in one launch (the plan batches a backward pass's 26 layers into 4)
  *   i: 0 B, 1 n_units (<= 7), then per unit u at 2+4u: S offset (floats from p[0]), C, dgamma offset, dbeta offset (floats from p[1])

@@ -107,6 +107,10 @@ class Sim:
         else:
             dst.copy_(val.to(dst.dtype))
 
+    def round(self, v):
+        """fp32 value as it would read back after a store in the plan's element type"""
+        return v.to(self.T).float()
+
     def flat(self, ref):
         return ref.buf.tensor.view(-1)[ref.off:]
 
@@ -196,8 +200,11 @@ class Sim:
         g = fold(self.rd(r.p[0], C, l1, c1), pm, fold1)
         if r.p[1] is not None:
             g = g + fold(self.rd(r.p[1], C, l2, c2), pm, fold2)
-        self.wr(r.p[6], C, lG, cG, g, interior_only=True)
-        g = self.rd(r.p[6], C, lG, cG)[:, 1:-1, 1:-1]           # as stored (rounded in bf16 mode)
+        if r.p[6] is not None:
+            self.wr(r.p[6], C, lG, cG, g, interior_only=True)
+            g = self.rd(r.p[6], C, lG, cG)[:, 1:-1, 1:-1]       # as stored (rounded in bf16 mode)
+        else:                                                   # single source, no G: pass 2 recomputes the same rounded value
+            g = self.round(g)
         raw = self.rd(r.p[2], C, lr_, cr)[:, 1:-1, 1:-1]
         u, xh = self._u(raw, r.p[3].buf.tensor, self.flat(r.p[4])[:C], self.flat(r.p[5])[:C])
         dz = g * self._drop(B, C, site, seed, r.f[0]) * act_bwd(u, act)
@@ -209,7 +216,11 @@ class Sim:
 
     def op_INACT_BWD_APPLY(self, r):
         B, H, W, C, lG, cG, lr_, cr, ld, cd, act, site, seed = r.i[:13]
-        g = self.rd(r.p[0], C, lG, cG)[:, 1:-1, 1:-1]
+        do_fold, pm = (r.i[13], r.i[14]) if len(r.i) > 14 else (0, 0)
+        if do_fold:                                             # p[0] is the unit's single gradient source, ring not yet folded
+            g = self.round(fold(self.rd(r.p[0], C, lG, cG), pm, 1))
+        else:
+            g = self.rd(r.p[0], C, lG, cG)[:, 1:-1, 1:-1]
         raw = self.rd(r.p[1], C, lr_, cr)[:, 1:-1, 1:-1]
         stats = r.p[2].buf.tensor
         gamma = self.flat(r.p[3])[:C]

@@ -261,6 +261,8 @@ FNET_DECL_OP(fnet_op_affine_grad);
 FNET_DECL_OP(fnet_op_affine_grad_multi);
 FNET_DECL_OP(fnet_op_metrics);
 FNET_DECL_OP(fnet_op_gather_batch);
+FNET_DECL_OP(fnet_op_pool2x);
+FNET_DECL_OP(fnet_op_pool2x_bwd);
 FNET_DECL_OP(fnet_op_fold_sum);
 FNET_DECL_OP(fnet_op_bias_grad);
 FNET_DECL_OP(fnet_op_zero_insert);

@@ -738,6 +738,75 @@ __global__ __launch_bounds__(256) void k_upsample2x_bwd(const T* g, T* dst, int 
     o.store(dst + (((size_t)n * hp + i + 1) * wp + j + 1) * ldc_d + coff_d + c0);
 }
 
+// ------------------------------------------------------------------ POOL2X (nn.AvgPool2d(2) / nn.MaxPool2d(2), unet.py:93-94)
+// dst (h, w) whole padded domain: interior = the 2x2 window's mean or max, ring = the padding values of the conv that follows.
+template <typename T>
+__global__ __launch_bounds__(256) void k_pool2x(const T* src, T* dst, int B, int h, int w, int C, int ldc_s, int coff_s, int ldc_d, int coff_d,
+                                                int mode, int pm) {
+    const int hp = h + 2, wp = w + 2, Wp = 2 * w + 2, groups = C >> 3;
+    const int row = blockIdx.x;
+    const int n = row / hp, y = row % hp;
+    const int item = blockIdx.y * kThreads + threadIdx.x;
+    if (item >= wp * groups) return;
+    const int x = item / groups, cg = item - x * groups, c0 = cg * 8;
+    const int i = pad_src(y - 1, h, pm), j = pad_src(x - 1, w, pm);
+    Vec8<T> o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o.v[k] = 0.f;
+    if (i >= 0 && j >= 0) {
+        const T* s = src + (((size_t)n * (2 * h + 2) + 2 * i + 1) * Wp + 2 * j + 1) * ldc_s + coff_s + c0;
+        Vec8<T> a, b, c, e;
+        a.load(s); b.load(s + ldc_s); c.load(s + (size_t)Wp * ldc_s); e.load(s + (size_t)(Wp + 1) * ldc_s);
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            o.v[k] = mode ? fmaxf(fmaxf(a.v[k], b.v[k]), fmaxf(c.v[k], e.v[k])) : 0.25f * ((a.v[k] + b.v[k]) + (c.v[k] + e.v[k]));
+    }
+    o.store(dst + ((size_t)row * wp + x) * ldc_d + coff_d + c0);
+}
+
+// adjoint: dst (2h, 2w) whole padded domain, ring 0.  avg: a quarter of the (folded) window gradient to each of its four
+// pixels; max: all of it to the FIRST maximum of the window in row-major order (torch's max_pool2d keeps the first index
+// whose value is greater than the running maximum), found again from the forward input x.
+template <typename T>
+__global__ __launch_bounds__(256) void k_pool2x_bwd(const T* g, const T* xin, T* dst, int B, int h, int w, int C, int ldc_g, int coff_g, int ldc_x,
+                                                    int coff_x, int ldc_d, int coff_d, int fold, int mode, int pm) {
+    const int H = 2 * h, W = 2 * w, Hp = H + 2, Wp = W + 2, groups = C >> 3;
+    const int row = blockIdx.x;
+    const int n = row / Hp, y = row % Hp;
+    const int item = blockIdx.y * kThreads + threadIdx.x;
+    if (item >= Wp * groups) return;
+    const int x = item / groups, cg = item - x * groups, c0 = cg * 8;
+    Vec8<T> o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o.v[k] = 0.f;
+    if (y >= 1 && y <= H && x >= 1 && x <= W) {
+        const int i = (y - 1) >> 1, j = (x - 1) >> 1;
+        float gv[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) gv[k] = 0.f;
+        fold_read8<T>(g + coff_g + c0, n, i, j, h, w, ldc_g, pm, fold, gv);
+        if (!mode) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o.v[k] = 0.25f * gv[k];
+        } else {
+            const T* s = xin + (((size_t)n * Hp + 2 * i + 1) * Wp + 2 * j + 1) * ldc_x + coff_x + c0;
+            Vec8<T> q[4];
+            q[0].load(s); q[1].load(s + ldc_x); q[2].load(s + (size_t)Wp * ldc_x); q[3].load(s + (size_t)(Wp + 1) * ldc_x);
+            const int me = ((y - 1) & 1) * 2 + ((x - 1) & 1);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                int arg = 0;
+                float m = q[0].v[k];
+#pragma unroll
+                for (int r = 1; r < 4; ++r)
+                    if (q[r].v[k] > m || q[r].v[k] != q[r].v[k]) { m = q[r].v[k]; arg = r; }
+                o.v[k] = arg == me ? gv[k] : 0.f;
+            }
+        }
+    }
+    o.store(dst + ((size_t)row * Wp + x) * ldc_d + coff_d + c0);
+}
+
 // ------------------------------------------------------------------ SUBSAMPLE_BIAS (stride-2 conv = stride-1 conv sampled at even pixels)
 template <typename T>
 __global__ __launch_bounds__(256) void k_subsample_bias(const T* src, const float* bias, T* dst, int B, int H, int W, int C, int ldc_s, int coff_s,
@@ -1058,6 +1127,34 @@ int fnet_op_upsample2x_bwd(const FnetOp& op, hipStream_t st) {
     DISPATCH_T(op.dtype, hipLaunchKernelGGL(k_upsample2x_bwd<T>, row_grid(B * h, w * (C / 8)), dim3(kThreads), 0, st,
                                             (const T*)op.p[0], (T*)op.p[1], B, h, w, C, op.i[4], op.i[5], op.i[6], op.i[7],
                                             op.i[8], op.i[9], op.i[10]));
+    FNET_LAUNCH_CHECK();
+    return FNET_OK;
+}
+
+// POOL2X  i: 0 B,1 h,2 w,3 C,4 ldc_s,5 coff_s,6 ldc_d,7 coff_d,8 mode (0 avg,1 max),9 pm; p: 0 src (2h,2w),1 dst (h,w, whole padded domain)
+int fnet_op_pool2x(const FnetOp& op, hipStream_t st) {
+    const int B = op.i[0], h = op.i[1], w = op.i[2], C = op.i[3];
+    FNET_CHECK_ARG(B > 0 && h >= 1 && w >= 1 && (op.i[8] == 0 || op.i[8] == 1));
+    FNET_CHECK_ARG(vec_ok((void*)op.p[0], op.i[4], op.i[5], C, op.dtype));
+    FNET_CHECK_ARG(vec_ok((void*)op.p[1], op.i[6], op.i[7], C, op.dtype));
+    DISPATCH_T(op.dtype, hipLaunchKernelGGL(k_pool2x<T>, row_grid(B * (h + 2), (w + 2) * (C / 8)), dim3(kThreads), 0, st,
+                                            (const T*)op.p[0], (T*)op.p[1], B, h, w, C, op.i[4], op.i[5], op.i[6], op.i[7], op.i[8],
+                                            op.i[9]));
+    FNET_LAUNCH_CHECK();
+    return FNET_OK;
+}
+
+// POOL2X_BWD  i: 0 B,1 h,2 w,3 C,4 ldc_g,5 coff_g,6 ldc_x,7 coff_x,8 ldc_d,9 coff_d,10 fold,11 mode,12 pm
+//             p: 0 g (h,w),1 x = forward input (2h,2w; max only, else 0),2 dst (2h,2w, whole padded domain, ring 0)
+int fnet_op_pool2x_bwd(const FnetOp& op, hipStream_t st) {
+    const int B = op.i[0], h = op.i[1], w = op.i[2], C = op.i[3];
+    FNET_CHECK_ARG(B > 0 && h >= 1 && w >= 1 && (op.i[11] == 0 || op.i[11] == 1) && (op.i[10] == 0 || op.i[10] == 1));
+    FNET_CHECK_ARG(vec_ok((void*)op.p[0], op.i[4], op.i[5], C, op.dtype));
+    if (op.i[11]) FNET_CHECK_ARG(vec_ok((void*)op.p[1], op.i[6], op.i[7], C, op.dtype));
+    FNET_CHECK_ARG(vec_ok((void*)op.p[2], op.i[8], op.i[9], C, op.dtype));
+    DISPATCH_T(op.dtype, hipLaunchKernelGGL(k_pool2x_bwd<T>, row_grid(B * (2 * h + 2), (2 * w + 2) * (C / 8)), dim3(kThreads), 0, st,
+                                            (const T*)op.p[0], (const T*)op.p[1], (T*)op.p[2], B, h, w, C, op.i[4], op.i[5], op.i[6],
+                                            op.i[7], op.i[8], op.i[9], op.i[10], op.i[11], op.i[12]));
     FNET_LAUNCH_CHECK();
     return FNET_OK;
 }

@@ -25,6 +25,8 @@ static int dispatch_op(const FnetOp& op, hipStream_t st) {
         case FNET_OP_AFFINE_GRAD_MULTI: return fnet_op_affine_grad_multi(op, st);
         case FNET_OP_METRICS: return fnet_op_metrics(op, st);
         case FNET_OP_GATHER_BATCH: return fnet_op_gather_batch(op, st);
+        case FNET_OP_POOL2X: return fnet_op_pool2x(op, st);
+        case FNET_OP_POOL2X_BWD: return fnet_op_pool2x_bwd(op, st);
         case FNET_OP_FOLD_SUM: return fnet_op_fold_sum(op, st);
         case FNET_OP_BIAS_GRAD: return fnet_op_bias_grad(op, st);
         case FNET_OP_ZERO_INSERT: return fnet_op_zero_insert(op, st);

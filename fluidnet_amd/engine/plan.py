@@ -186,8 +186,8 @@ def check_supported(cfg, H: int, W: int) -> None:
     bad = []
     if cfg.norm != "instance":
         bad.append(f"norm={cfg.norm!r} (only 'instance')")
-    if cfg.downsample != "stride":
-        bad.append(f"downsample={cfg.downsample!r} (only 'stride')")
+    if cfg.downsample not in ("stride", "avgpool", "maxpool"):
+        bad.append(f"downsample={cfg.downsample!r}")
     if cfg.upsample not in ("bilinear", "nearest"):
         bad.append(f"upsample={cfg.upsample!r} (only 'bilinear'/'nearest')")
     if cfg.in_channels != 6:
@@ -409,13 +409,24 @@ class PlanBuilder:
             else:
                 d["block"] = self._conv_block(ops, tn, f"downs.{L}.block", x, C, skip, False, site); site += 1
                 d["res"] = None
-            full = self.tmp(h, w, C)
-            name = f"downs.{L}.down"
-            self.e_conv(ops, skip, self.convs[name]["Wf"], None, PV(full, C), C, C, tag=name)
             dn = self.pbuf(f"{tn}/dn{L}", h // 2, w // 2, C)
-            self.op(ops, "SUBSAMPLE_BIAS", [B, h, w, C, C, 0, C, 0, self.pm], p=[Ref(full), self.pref(name + ".bias"), Ref(dn)], tag=name)
-            self.release(full)
-            d["down"] = PlainConv(name, skip, PV(dn, C), 2)
+            if cfg.downsample == "stride":
+                full = self.tmp(h, w, C)
+                name = f"downs.{L}.down"
+                self.e_conv(ops, skip, self.convs[name]["Wf"], None, PV(full, C), C, C, tag=name)
+                self.op(ops, "SUBSAMPLE_BIAS", [B, h, w, C, C, 0, C, 0, self.pm], p=[Ref(full), self.pref(name + ".bias"), Ref(dn)], tag=name)
+                self.release(full)
+                d["down"] = PlainConv(name, skip, PV(dn, C), 2)
+            else:
+                # Sequential(pool, conv3x3 + bias) (unet.py:93-94): the pooled tensor is kept, the conv's wgrad reads it
+                name = f"downs.{L}.down.1"
+                pooled = self.pbuf(f"{tn}/pool{L}", h // 2, w // 2, C)
+                self.op(ops, "POOL2X", [B, h // 2, w // 2, C, skip.ldc, skip.coff, C, 0, 1 if cfg.downsample == "maxpool" else 0, self.pm],
+                        p=[skip.ref, Ref(pooled)], tag=f"downs.{L}.down.0")
+                self.e_conv(ops, PV(pooled, C), self.convs[name]["Wf"], self.pref(name + ".bias"), PV(dn, C), C, C, tag=name)
+                self.op(ops, "PAD_RING", [B, h // 2, w // 2, C, C, 0, self.pm], p=[Ref(dn)])
+                d["down"] = PlainConv(name, PV(pooled, C), PV(dn, C), 1)
+                d["pool_in"] = skip
             t.downs.append(d)
             x = d["down"].out
             h, w, ch = h // 2, w // 2, C
@@ -584,6 +595,14 @@ class PlanBuilder:
             d = t.downs[L]
             C = d["C"]
             g = self._plain_conv_bwd(ops, d["down"], srcs, True)
+            if "pool_in" in d:
+                xs = d["pool_in"]
+                mx = cfg.downsample == "maxpool"
+                gfull = self.tmp(xs.H, xs.W, C)
+                self.op(ops, "POOL2X_BWD", [B, xs.H // 2, xs.W // 2, C, g.pv.ldc, g.pv.coff, xs.ldc, xs.coff, C, 0, g.fold, 1 if mx else 0, self.pm],
+                        p=[g.pv.ref, xs.ref if mx else None, Ref(gfull)], tag=f"downs.{L}.down.0")
+                self.release(g.pv.buf)
+                g = GradSrc(PV(gfull, C), 0)
             srcs = [g, GradSrc(PV(dcat[L], C, C), 1)]
             if d["res"] is not None:
                 srcs = self._block_bwd(ops, d["res"], srcs, True)

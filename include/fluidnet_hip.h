@@ -111,6 +111,8 @@ enum FnetOpCode {
     FNET_OP_AFFINE_GRAD_MULTI = 29,
     FNET_OP_METRICS = 30,
     FNET_OP_GATHER_BATCH = 31,
+    FNET_OP_POOL2X = 32,          /* 2x2 average / max pooling of the pooled `down` variants (unet.py:93-94) */
+    FNET_OP_POOL2X_BWD = 33,
     FNET_OP_COUNT_
 };
 

@@ -84,6 +84,12 @@
  * BIAS_GRAD         i: 0 B, 1 H, 2 W, 3 C, 4 ldc, 5 coff; p: 0 d P, 1 dbias (+=)
  * ZERO_INSERT       <- adjoint of SUBSAMPLE_BIAS; i: 0 B, 1 h, 2 w, 3 C, 4 ldc_s, 5 coff_s, 6 ldc_d, 7 coff_d
  *                   p: 0 src P (h,w), 1 dst P (2h,2w; whole padded domain written)
+ * POOL2X            <- nn.AvgPool2d(2) / nn.MaxPool2d(2) of the pooled `down` variants (unet.py:93-94)
+ *                   i: 0 B, 1 h, 2 w (output size), 3 C, 4 ldc_s, 5 coff_s, 6 ldc_d, 7 coff_d, 8 mode (0 avg, 1 max), 9 pm
+ *                   p: 0 src P (2h,2w), 1 dst P (h,w; whole padded domain written, ring per pm)
+ * POOL2X_BWD        i: 0 B, 1 h, 2 w, 3 C, 4 ldc_g, 5 coff_g, 6 ldc_x, 7 coff_x, 8 ldc_d, 9 coff_d, 10 fold, 11 mode, 12 pm
+ *                   p: 0 g P (h,w), 1 x P (2h,2w) = POOL2X's input (max only: the gradient goes to the first maximum of the
+ *                      window in row-major order, as torch's max_pool2d) | 0, 2 dst P (2h,2w; whole padded domain, ring 0)
  * UPSAMPLE2X_BWD    i: 0 B, 1 h, 2 w, 3 C, 4 ldc_g, 5 coff_g, 6 ldc_d, 7 coff_d, 8 fold, 9 mode, 10 pm
  *                   p: 0 g P (2h,2w), 1 dst P (h,w interior)
  * UNPACK_GRAD       i: 0 B, 1 H, 2 W, 3 ldc, 4 nch, 5 pm; p: 0 d_in_pad P, 1 dx fp32 [B,nch,H,W]

@@ -299,6 +299,35 @@ class Sim:
             x = x + self.flat(r.p[1])[:C]
         self.wr(r.p[2], C, ld, cd, pad_from_interior(x, pm))
 
+    def op_POOL2X(self, r):
+        B, h, w, C, ls, cs, ld, cd, mode, pm = r.i[:10]
+        x = self.rd(r.p[0], C, ls, cs)[:, 1:-1, 1:-1]
+        q = [x[:, 0::2, 0::2], x[:, 0::2, 1::2], x[:, 1::2, 0::2], x[:, 1::2, 1::2]]
+        y = torch.maximum(torch.maximum(q[0], q[1]), torch.maximum(q[2], q[3])) if mode else 0.25 * ((q[0] + q[1]) + (q[2] + q[3]))
+        self.wr(r.p[1], C, ld, cd, pad_from_interior(y, pm))
+
+    def op_POOL2X_BWD(self, r):
+        B, h, w, C, lg, cg, lx, cx, ld, cd, do_fold, mode, pm = r.i[:13]
+        g = fold(self.rd(r.p[0], C, lg, cg), pm, do_fold)
+        out = torch.zeros(B, 2 * h + 2, 2 * w + 2, C)
+        inner = out[:, 1:-1, 1:-1]
+        sl = [(0, 0), (0, 1), (1, 0), (1, 1)]
+        if not mode:
+            for (a, b) in sl:
+                inner[:, a::2, b::2] = 0.25 * g
+        else:
+            x = self.rd(r.p[1], C, lx, cx)[:, 1:-1, 1:-1]
+            q = torch.stack([x[:, a::2, b::2] for (a, b) in sl])
+            arg = torch.zeros_like(q[0], dtype=torch.long)
+            m = q[0].clone()
+            for k in range(1, 4):                         # first maximum in row-major order wins (torch max_pool2d)
+                better = q[k] > m
+                arg = torch.where(better, torch.full_like(arg, k), arg)
+                m = torch.where(better, q[k], m)
+            for k, (a, b) in enumerate(sl):
+                inner[:, a::2, b::2] = torch.where(arg == k, g, torch.zeros_like(g))
+        self.wr(r.p[2], C, ld, cd, out)
+
     def op_ZERO_INSERT(self, r):
         B, h, w, C, ls, cs, ld, cd = r.i[:8]
         x = self.rd(r.p[0], C, ls, cs)[:, 1:-1, 1:-1]

@@ -34,6 +34,9 @@ CASES = [
     ("fp32-ref-reflect-central", dict(act="silu", upsample="nearest"), "reflect", "fp32", "ref", 8),
     ("bf16-mfma-circular", dict(act="relu", output_activation="sigmoid_tanh", use_residual=False), "circular", "bf16", "mfma", 16),
     ("bf16-mfma-zeros-depth3", dict(depth=3, act="leaky_relu"), "zeros", "bf16", "mfma", 16),
+    ("fp32-ref-avgpool", dict(downsample="avgpool"), "replicate", "fp32", "ref", 8),
+    ("bf16-mfma-maxpool-reflect", dict(downsample="maxpool", dropout=0.1), "reflect", "bf16", "mfma", 16),
+    ("bf16-mfma-avgpool-depth3", dict(downsample="avgpool", depth=3), "zeros", "bf16", "mfma", 16),
 ]
 
 

@@ -87,6 +87,13 @@ def test_mid0_relu_depth3():
     run_case(tiny_cfg(bottleneck_blocks=0, act="relu", depth=3), loss_c2(32), 1, 32, 1)
 
 
+@pytest.mark.parametrize("mode,pm", [("avgpool", "replicate"), ("maxpool", "zeros"), ("maxpool", "reflect"), ("avgpool", "circular")])
+def test_pooled_downsample(mode, pm):
+    """Sequential(pool, conv3x3) `down` of UNet_small / UNet_small-medium / UNet_large (unet.py:93-94)"""
+    # K = 1 for max: the argmax is discontinuous, a second application amplifies fp32 noise past the K <= 2 gradient bar
+    run_case(tiny_cfg(downsample=mode, padding_mode=pm), loss_c2(16, padding_mode=pm), 2, 16, 2 if mode == "avgpool" else 1)
+
+
 def test_dropout_hash_matches_injected_masks():
     run_case(tiny_cfg(dropout=0.3), loss_c2(16), 3, 16, 2, dropout_seed=1234)
 

@@ -263,6 +263,8 @@ FNET_DECL_OP(fnet_op_metrics);
 FNET_DECL_OP(fnet_op_gather_batch);
 FNET_DECL_OP(fnet_op_pool2x);
 FNET_DECL_OP(fnet_op_pool2x_bwd);
+FNET_DECL_OP(fnet_op_norm_combine);
+FNET_DECL_OP(fnet_op_norm_combine_bwd);
 FNET_DECL_OP(fnet_op_fold_sum);
 FNET_DECL_OP(fnet_op_bias_grad);
 FNET_DECL_OP(fnet_op_zero_insert);

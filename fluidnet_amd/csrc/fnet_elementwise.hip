@@ -271,6 +271,76 @@ __global__ __launch_bounds__(256) void k_in_finalize_tiles(const float2* part, f
     stats[i] = make_float2(mean, rsqrtf(var + eps));
 }
 
+// ------------------------------------------------------------------ NORM_COMBINE (BatchNorm2d / GroupNorm on top of the per-(n,c) statistics)
+// IN_STATS leaves (mean, rstd) per (n, c).  With var = 1/rstd^2 - eps and E[x^2] = var + mean^2 those pool exactly: over n
+// (BatchNorm2d in training mode, unet.py:20-21; also updates the running statistics, momentum 0.1, unbiased variance) or over the
+// channels of a group (GroupNorm, unet.py:24-28).  kind 3 = BatchNorm2d in eval mode: statistics are the running ones.
+// The pooled (mean, rstd) is written back to every (n, c) it covers, so APPLY and the adjoint kernels are unchanged.
+__global__ __launch_bounds__(256) void k_norm_combine(float2* st, float* rmean, float* rvar, int B, int C, int kind, int gs, float eps,
+                                                      float momentum, float count) {
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    if (kind == 1) {
+        if (i >= C) return;
+        float m = 0.f, e2 = 0.f;
+        for (int n = 0; n < B; ++n) {
+            const float2 v = st[(size_t)n * C + i];
+            const float var = fmaxf(1.f / (v.y * v.y) - eps, 0.f);
+            m += v.x; e2 += var + v.x * v.x;
+        }
+        m /= (float)B; e2 /= (float)B;
+        const float var = fmaxf(e2 - m * m, 0.f);
+        const float2 o = make_float2(m, rsqrtf(var + eps));
+        for (int n = 0; n < B; ++n) st[(size_t)n * C + i] = o;
+        if (rmean) {
+            rmean[i] = (1.f - momentum) * rmean[i] + momentum * m;
+            rvar[i] = (1.f - momentum) * rvar[i] + momentum * var * (count / fmaxf(count - 1.f, 1.f));
+        }
+    } else if (kind == 2) {
+        const int ng = C / gs;
+        if (i >= B * ng) return;
+        const int n = i / ng, g = i - n * ng;
+        float2* s = st + (size_t)n * C + g * gs;
+        float m = 0.f, e2 = 0.f;
+        for (int c = 0; c < gs; ++c) {
+            const float2 v = s[c];
+            const float var = fmaxf(1.f / (v.y * v.y) - eps, 0.f);
+            m += v.x; e2 += var + v.x * v.x;
+        }
+        m /= (float)gs; e2 /= (float)gs;
+        const float2 o = make_float2(m, rsqrtf(fmaxf(e2 - m * m, 0.f) + eps));
+        for (int c = 0; c < gs; ++c) s[c] = o;
+    } else {
+        if (i >= B * C) return;
+        const int c = i % C;
+        st[i] = make_float2(rmean[c], rsqrtf(rvar[c] + eps));
+    }
+}
+// adjoint side: Sw[n][c] = the gamma-weighted mean of S = (sum dz, sum dz*xhat) over the normalisation group of (n, c):
+// kind 1 gamma_c * mean_n S[n][c]; kind 2 mean over the group's channels c' of gamma_c' S[n][c']; kind 3 zero (eval-mode
+// BatchNorm2d is an affine map: nothing to centre).  S itself stays per (n, c) for AFFINE_GRAD.
+__global__ __launch_bounds__(256) void k_norm_combine_bwd(const float2* S, const float* gamma, float2* Sw, int B, int C, int kind, int gs) {
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    if (kind == 1) {
+        if (i >= C) return;
+        float a = 0.f, b = 0.f;
+        for (int n = 0; n < B; ++n) { const float2 v = S[(size_t)n * C + i]; a += v.x; b += v.y; }
+        const float g = gamma[i] / (float)B;
+        const float2 o = make_float2(a * g, b * g);
+        for (int n = 0; n < B; ++n) Sw[(size_t)n * C + i] = o;
+    } else if (kind == 2) {
+        const int ng = C / gs;
+        if (i >= B * ng) return;
+        const int n = i / ng, g = i - n * ng;
+        float a = 0.f, b = 0.f;
+        for (int c = 0; c < gs; ++c) { const float2 v = S[(size_t)n * C + g * gs + c]; const float w = gamma[g * gs + c]; a += w * v.x; b += w * v.y; }
+        const float2 o = make_float2(a / (float)gs, b / (float)gs);
+        for (int c = 0; c < gs; ++c) Sw[(size_t)n * C + g * gs + c] = o;
+    } else {
+        if (i >= B * C) return;
+        Sw[i] = make_float2(0.f, 0.f);
+    }
+}
+
 // ------------------------------------------------------------------ APPLY
 // dst[n,y,x,c] = act(gamma*(raw[src]-mean)*rstd+beta) * drop(n,c) + res[src], over the padded domain
 template <typename T, int ACT>
@@ -488,7 +558,9 @@ __global__ __launch_bounds__(256) void k_inact_bwd_reduce(const T* __restrict__ 
 // ------------------------------------------------------------------ INACT_BWD_APPLY (pass 2)
 // d_raw = gamma*rstd*(dz - S1/HW - xhat*S2/HW) on the interior, 0 on the ring (so that d_raw can feed
 // the flattened dgrad / wgrad convolutions directly).
-template <typename T, int ACT>
+// WS ("weighted sums", BatchNorm2d / GroupNorm): S holds what NORM_COMBINE_BWD made of the per-(n,c) sums -- their gamma-weighted
+// mean over the normalisation group -- and d_raw = gamma*rstd*dz - rstd*(S1'/HW + xhat*S2'/HW).
+template <typename T, int ACT, bool WS>
 __global__ __launch_bounds__(256) void k_inact_bwd_apply(const T* __restrict__ G, const T* __restrict__ raw, const float2* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta,
                                   const float2* __restrict__ S, T* __restrict__ draw, int H, int W, int C, int ldc_G, int coff_G, int ldc_raw,
                                   int coff_raw, int ldc_d, int coff_d, int act, uint32_t site, uint32_t seed, float drop_p,
@@ -507,9 +579,9 @@ __global__ __launch_bounds__(256) void k_inact_bwd_apply(const T* __restrict__ G
         xa[k] = ms.y; xb[k] = -ms.x * ms.y;
         gam[k] = gamma[c0 + k]; bet[k] = beta[c0 + k];
         dsc[k] = drop_scale(seed, site, n, c0 + k, drop_p);
-        k0[k] = gam[k] * ms.y;                            // out = k0*(dz - k1 - xh*k2)
-        k1[k] = ss.x * inv;
-        k2[k] = ss.y * inv;
+        k0[k] = gam[k] * ms.y;                            // out = k0*(dz - k1 - xh*k2); WS: k0*dz - (k1 + xh*k2)
+        k1[k] = ss.x * inv * (WS ? ms.y : 1.f);
+        k2[k] = ss.y * inv * (WS ? ms.y : 1.f);
     }
     const size_t img = (size_t)n * Hp * Wp;
     const T* Gbase = G + img * ldc_G + coff_G + c0;
@@ -549,7 +621,7 @@ __global__ __launch_bounds__(256) void k_inact_bwd_apply(const T* __restrict__ G
                 const float xh = fmaf(r[u].v[k], xa[k], xb[k]);
                 const float uu = fmaf(xh, gam[k], bet[k]);
                 const float dz = g[u].v[k] * dsc[k] * act_bwd_t<ACT>(uu);
-                o.v[k] = keep_bits(k0[k] * (dz - k1[k] - xh * k2[k]), keep[u]);
+                o.v[k] = keep_bits(WS ? fmaf(k0[k], dz, -fmaf(xh, k2[k], k1[k])) : k0[k] * (dz - k1[k] - xh * k2[k]), keep[u]);
             }
             o.store_nt(dbase + (size_t)(p + u * ps) * ldc_d);
         }
@@ -1027,7 +1099,8 @@ int fnet_op_inact_bwd_reduce(const FnetOp& op, hipStream_t st) {
 }
 
 // INACT_BWD_APPLY  i: 0 B,1 H,2 W,3 C,4 ldc_G,5 coff_G,6 ldc_raw,7 coff_raw,8 ldc_d,9 coff_d,10 act,11 drop site,12 seed,
-//                     13 fold (p[0] is the unit's single gradient source, ring not yet folded),14 pm
+//                     13 fold (p[0] is the unit's single gradient source, ring not yet folded),14 pm,
+//                     15 weighted S (BatchNorm2d / GroupNorm: p[5] = output of NORM_COMBINE_BWD)
 //                  f: 0 drop_p; p: 0 G,1 raw,2 stats,3 gamma,4 beta,5 S,6 d_raw out
 int fnet_op_inact_bwd_apply(const FnetOp& op, hipStream_t st) {
     const int B = op.i[0], H = op.i[1], W = op.i[2], C = op.i[3];
@@ -1039,11 +1112,43 @@ int fnet_op_inact_bwd_apply(const FnetOp& op, hipStream_t st) {
     FNET_CHECK_ARG((op.i[13] == 0 || op.i[13] == 1) && op.i[14] >= 0 && op.i[14] <= 3);
     int chunks;
     const int per = cg_pixels_per_block((H + 2) * (W + 2), B, C, &chunks, 768);
-    DISPATCH_ACT(op.i[10], DISPATCH_T(op.dtype, hipLaunchKernelGGL((k_inact_bwd_apply<T, ACT>), dim3(chunks, B), dim3(kThreads), 0,
-                                            st, (const T*)op.p[0], (const T*)op.p[1], (const float2*)op.p[2],
-                                            (const float*)op.p[3], (const float*)op.p[4], (const float2*)op.p[5],
-                                            (T*)op.p[6], H, W, C, op.i[4], op.i[5], op.i[6], op.i[7], op.i[8], op.i[9],
-                                            op.i[10], (uint32_t)op.i[11], (uint32_t)op.i[12], op.f[0], per, op.i[13], op.i[14])));
+#define INACT_APPLY_LAUNCH(WS_)                                                                                                     \
+    DISPATCH_ACT(op.i[10], DISPATCH_T(op.dtype, hipLaunchKernelGGL((k_inact_bwd_apply<T, ACT, WS_>), dim3(chunks, B), dim3(kThreads), 0, \
+                                            st, (const T*)op.p[0], (const T*)op.p[1], (const float2*)op.p[2],                        \
+                                            (const float*)op.p[3], (const float*)op.p[4], (const float2*)op.p[5],                    \
+                                            (T*)op.p[6], H, W, C, op.i[4], op.i[5], op.i[6], op.i[7], op.i[8], op.i[9],              \
+                                            op.i[10], (uint32_t)op.i[11], (uint32_t)op.i[12], op.f[0], per, op.i[13], op.i[14])))
+    FNET_CHECK_ARG(op.i[15] == 0 || op.i[15] == 1);
+    if (op.i[15]) { INACT_APPLY_LAUNCH(true); } else { INACT_APPLY_LAUNCH(false); }
+#undef INACT_APPLY_LAUNCH
+    FNET_LAUNCH_CHECK();
+    return FNET_OK;
+}
+
+// NORM_COMBINE  i: 0 B,1 C,2 kind (1 batch/training, 2 group, 3 batch/eval),3 channels per group (kind 2),4 H*W
+//               f: 0 eps,1 momentum; p: 0 stats float2[B][C] (in place),1 running_mean|0,2 running_var|0 (kind 1: updated when given;
+//               kind 3: read)
+int fnet_op_norm_combine(const FnetOp& op, hipStream_t st) {
+    const int B = op.i[0], C = op.i[1], kind = op.i[2], gs = op.i[3];
+    FNET_CHECK_ARG(B > 0 && C > 0 && kind >= 1 && kind <= 3 && op.p[0] && op.i[4] > 0);
+    FNET_CHECK_ARG(kind != 2 || (gs >= 1 && C % gs == 0));
+    FNET_CHECK_ARG(kind != 3 || (op.p[1] && op.p[2]));
+    FNET_CHECK_ARG((op.p[1] == 0) == (op.p[2] == 0));
+    const int items = kind == 1 ? C : kind == 2 ? B * (C / gs) : B * C;
+    hipLaunchKernelGGL(k_norm_combine, dim3((items + kThreads - 1) / kThreads), dim3(kThreads), 0, st, (float2*)op.p[0], (float*)op.p[1],
+                       (float*)op.p[2], B, C, kind, gs, op.f[0], op.f[1], (float)B * (float)op.i[4]);
+    FNET_LAUNCH_CHECK();
+    return FNET_OK;
+}
+
+// NORM_COMBINE_BWD  i: 0 B,1 C,2 kind,3 channels per group; p: 0 S float2[B][C],1 gamma,2 Sw float2[B][C] out
+int fnet_op_norm_combine_bwd(const FnetOp& op, hipStream_t st) {
+    const int B = op.i[0], C = op.i[1], kind = op.i[2], gs = op.i[3];
+    FNET_CHECK_ARG(B > 0 && C > 0 && kind >= 1 && kind <= 3 && op.p[0] && op.p[1] && op.p[2]);
+    FNET_CHECK_ARG(kind != 2 || (gs >= 1 && C % gs == 0));
+    const int items = kind == 1 ? C : kind == 2 ? B * (C / gs) : B * C;
+    hipLaunchKernelGGL(k_norm_combine_bwd, dim3((items + kThreads - 1) / kThreads), dim3(kThreads), 0, st, (const float2*)op.p[0],
+                       (const float*)op.p[1], (float2*)op.p[2], B, C, kind, gs);
     FNET_LAUNCH_CHECK();
     return FNET_OK;
 }

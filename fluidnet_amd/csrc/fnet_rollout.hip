@@ -63,7 +63,8 @@ FnetOp mkop(int code) {
     return o;
 }
 
-// ---- parameter table: state-dict order of the supported family (norm = instance, downsample = stride, no transposed conv)
+// ---- parameter table: the float tensors of the state dict, in its order (no transposed conv; BatchNorm2d contributes weight, bias,
+// running_mean, running_var -- its int64 num_batches_tracked is not part of the array)
 void add_param(Rollout& r, const std::string& name, long long n) {
     r.off[name] = r.n_params_padded;
     r.spans.push_back({r.n_params_padded, n});
@@ -77,6 +78,10 @@ void add_block(Rollout& r, const std::string& pre, int cin, int cout) {
         add_param(r, c + ".weight", (long long)cout * ci[k] * 9);
         add_param(r, n + ".weight", cout);
         add_param(r, n + ".bias", cout);
+        if (r.cfg.norm == 1) {
+            add_param(r, n + ".running_mean", cout);
+            add_param(r, n + ".running_var", cout);
+        }
         r.convs[c] = ConvEnt{cout, ci[k], ci[k], r.off[c + ".weight"], nullptr};
     }
 }
@@ -92,9 +97,10 @@ void build_params(Rollout& r) {
         const std::string d = "downs." + std::to_string(L);
         add_block(r, d + ".block", ch, oc);
         if (c.use_residual) add_block(r, d + ".res.b", oc, oc);
-        add_param(r, d + ".down.weight", (long long)oc * oc * 9);
-        add_param(r, d + ".down.bias", oc);
-        r.convs[d + ".down"] = ConvEnt{oc, oc, oc, r.off[d + ".down.weight"], nullptr};
+        const std::string dk = d + (c.downsample == 0 ? ".down" : ".down.1");     // Sequential(pool, conv) names its conv "1"
+        add_param(r, dk + ".weight", (long long)oc * oc * 9);
+        add_param(r, dk + ".bias", oc);
+        r.convs[d + ".down"] = ConvEnt{oc, oc, oc, r.off[dk + ".weight"], nullptr};
         skips.push_back(oc);
         ch = oc;
     }
@@ -118,18 +124,33 @@ void e_conv(Rollout& r, const PV& src, const ConvEnt& ce, const float* bias, con
     o.p[0] = (uint64_t)src.buf; o.p[1] = (uint64_t)ce.Wf; o.p[2] = (uint64_t)bias; o.p[3] = (uint64_t)dst.buf;
     r.frame.push_back(o);
 }
+int group_size(int groups, int ch) {          // channels per group of nn.GroupNorm as unet.py:24-28 builds it
+    int g = std::min(groups, ch);
+    while (g > 1 && ch % g) --g;
+    return ch / g;
+}
 PV unit(Rollout& r, const std::string& conv, const std::string& norm, const PV& xin, int cout, const PV* out, const PV* res) {
     const ConvEnt& ce = r.convs.at(conv);
     PV raw = r.pbuf(xin.H, xin.W, cout);
     float* st = (float*)r.alloc((size_t)r.B * cout * 2 * sizeof(float));
     PV o = out ? *out : r.pbuf(xin.H, xin.W, cout);
     e_conv(r, xin, ce, nullptr, raw, ce.cin_pad, cout);
-    {
+    if (r.cfg.norm != 1) {                      // eval-mode BatchNorm2d normalises with the running statistics alone
         FnetOp s = mkop(FNET_OP_IN_STATS);
         const int v[8] = {r.B, raw.H, raw.W, raw.C, raw.ldc, raw.coff, (int)r.scratch_floats, 0};
         memcpy(s.i, v, sizeof(v));
         s.f[0] = 1e-5f;
         s.p[0] = (uint64_t)raw.buf; s.p[1] = (uint64_t)st; s.p[2] = (uint64_t)r.stats_scratch;
+        r.frame.push_back(s);
+    }
+    if (r.cfg.norm != 0) {
+        FnetOp s = mkop(FNET_OP_NORM_COMBINE);
+        const int batch = r.cfg.norm == 1;
+        const int v[5] = {r.B, cout, batch ? 3 : 2, batch ? 1 : group_size(r.cfg.group_norm_groups, cout), raw.H * raw.W};
+        memcpy(s.i, v, sizeof(v));
+        s.f[0] = 1e-5f; s.f[1] = 0.1f;
+        s.p[0] = (uint64_t)st;
+        if (batch) { s.p[1] = (uint64_t)r.pp(norm + ".running_mean"); s.p[2] = (uint64_t)r.pp(norm + ".running_var"); }
         r.frame.push_back(s);
     }
     {
@@ -196,14 +217,29 @@ void build_frame(Rollout& r) {
         } else {
             conv_block(r, d + ".block", x, C, &skip, false);
         }
-        PV full = r.pbuf(h, w, C);
-        e_conv(r, skip, r.convs.at(d + ".down"), nullptr, full, C, C);
         PV dn = r.pbuf(h / 2, w / 2, C);
-        FnetOp o = mkop(FNET_OP_SUBSAMPLE_BIAS);
-        const int v[9] = {B, h, w, C, C, 0, C, 0, pm};
-        memcpy(o.i, v, sizeof(v));
-        o.p[0] = (uint64_t)full.buf; o.p[1] = (uint64_t)r.pp(d + ".down.bias"); o.p[2] = (uint64_t)dn.buf;
-        r.frame.push_back(o);
+        if (c.downsample == 0) {
+            PV full = r.pbuf(h, w, C);
+            e_conv(r, skip, r.convs.at(d + ".down"), nullptr, full, C, C);
+            FnetOp o = mkop(FNET_OP_SUBSAMPLE_BIAS);
+            const int v[9] = {B, h, w, C, C, 0, C, 0, pm};
+            memcpy(o.i, v, sizeof(v));
+            o.p[0] = (uint64_t)full.buf; o.p[1] = (uint64_t)r.pp(d + ".down.bias"); o.p[2] = (uint64_t)dn.buf;
+            r.frame.push_back(o);
+        } else {
+            PV pooled = r.pbuf(h / 2, w / 2, C);
+            FnetOp o = mkop(FNET_OP_POOL2X);
+            const int v[10] = {B, h / 2, w / 2, C, skip.ldc, skip.coff, C, 0, c.downsample == 2 ? 1 : 0, pm};
+            memcpy(o.i, v, sizeof(v));
+            o.p[0] = (uint64_t)skip.buf; o.p[1] = (uint64_t)pooled.buf;
+            r.frame.push_back(o);
+            e_conv(r, pooled, r.convs.at(d + ".down"), r.pp(d + ".down.1.bias"), dn, C, C);
+            FnetOp q = mkop(FNET_OP_PAD_RING);
+            const int u[7] = {B, h / 2, w / 2, C, C, 0, pm};
+            memcpy(q.i, u, sizeof(u));
+            q.p[0] = (uint64_t)dn.buf;
+            r.frame.push_back(q);
+        }
         cats.push_back(cat);
         Cs.push_back(C);
         x = dn;
@@ -253,6 +289,7 @@ int cfg_ok(const FnetUNetConfig& c, int B, int H, int W) {
     if (c.depth < 1 || c.depth > 6 || c.bottleneck_blocks < 0 || c.bottleneck_blocks > 8) return 0;
     if (c.act < 0 || c.act > 4 || c.padding_mode < 0 || c.padding_mode > 3 || c.upsample < 0 || c.upsample > 1) return 0;
     if (c.output_activation < 0 || c.output_activation > 1 || (c.use_residual != 0 && c.use_residual != 1)) return 0;
+    if (c.norm < 0 || c.norm > 2 || c.downsample < 0 || c.downsample > 2 || (c.norm == 2 && c.group_norm_groups < 1)) return 0;
     const int div = 1 << c.depth;
     if (B < 1 || B > 4096 || H % div || W % div || H / div < 2 || W / div < 2) return 0;
     return 1;

@@ -13,16 +13,27 @@ from . import runtime as rt
 
 class FnetUNetConfig(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in ("in_channels", "out_channels", "base_channels", "depth", "act", "padding_mode", "upsample",
-                                             "use_residual", "bottleneck_blocks", "output_activation")]
+                                             "use_residual", "bottleneck_blocks", "output_activation", "norm", "downsample",
+                                             "group_norm_groups")]
 
 
 def native_config(cfg) -> FnetUNetConfig:
     """UNetConfig (reference field names) -> the C struct; rejects what the native family does not cover."""
-    if cfg.norm != "instance" or cfg.downsample != "stride" or cfg.upsample not in ("nearest", "bilinear"):
-        raise NotImplementedError("native rollout covers norm='instance', downsample='stride', upsample in {'nearest','bilinear'}")
+    norms, downs = {"instance": 0, "batch": 1, "group": 2}, {"stride": 0, "avgpool": 1, "maxpool": 2}
+    if cfg.norm not in norms or cfg.downsample not in downs or cfg.upsample not in ("nearest", "bilinear"):
+        raise NotImplementedError("native rollout covers norm in {instance, batch, group}, downsample in {stride, avgpool, maxpool}, "
+                                  "upsample in {nearest, bilinear}")
     return FnetUNetConfig(cfg.in_channels, cfg.out_channels, cfg.base_channels, cfg.depth, rt.ACT[cfg.act], rt.PAD[cfg.padding_mode],
                           1 if cfg.upsample == "bilinear" else 0, 1 if cfg.use_residual else 0, cfg.bottleneck_blocks,
-                          rt.OUTACT[cfg.output_activation])
+                          rt.OUTACT[cfg.output_activation], norms[cfg.norm], downs[cfg.downsample], cfg.group_norm_groups)
+
+
+def checkpoint_floats(state_dict) -> np.ndarray:
+    """The array fnet_rollout_create takes: every floating-point tensor of a (reference-format) state dict, in its order, flattened
+    and concatenated -- BatchNorm2d's int64 num_batches_tracked is skipped."""
+    parts = [np.asarray(v.detach().cpu().float().numpy() if hasattr(v, "detach") else v, dtype=np.float32).reshape(-1)
+             for k, v in state_dict.items() if not k.endswith("num_batches_tracked")]
+    return np.concatenate(parts)
 
 
 def _f32(a: Optional[np.ndarray], shape) -> Optional[np.ndarray]:

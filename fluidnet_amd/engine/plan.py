@@ -164,6 +164,29 @@ def unet_param_shapes(cfg) -> "OrderedDict[str, Tuple[int, ...]]":
     return out
 
 
+def group_size(groups: int, ch: int) -> int:
+    """Channels per group of nn.GroupNorm as the reference builds it (unet.py:24-28): the largest g <= groups dividing ch."""
+    g = min(groups, ch)
+    while g > 1 and ch % g:
+        g -= 1
+    return ch // g
+
+
+def norm_state_layout(cfg) -> "Tuple[OrderedDict[str, int], int]":
+    """Offsets (floats) of BatchNorm2d's running_mean / running_var of every norm layer inside the flat norm-state buffer, in
+    state-dict order, each 32-B aligned; empty unless norm == 'batch'."""
+    offs: "OrderedDict[str, int]" = OrderedDict()
+    off = 0
+    if cfg.norm == "batch":
+        for k, s in unet_param_shapes(cfg).items():
+            if len(s) == 1 and ".n" in k and k.endswith(".weight"):
+                base = k[: -len(".weight")]
+                for leaf in ("running_mean", "running_var"):
+                    offs[f"{base}.{leaf}"] = off
+                    off = (off + s[0] + 7) // 8 * 8
+    return offs, off
+
+
 WG_PART = 9 * 32 * 32          # floats per wave partial of the weight-gradient kernel (fnet_conv_mfma.hip)
 
 
@@ -184,8 +207,8 @@ def wgrad_slab_parts(cfg) -> int:
 def check_supported(cfg, H: int, W: int) -> None:
     """The HIP engine covers the UNet_medium family; anything else fails loudly (no fallback)."""
     bad = []
-    if cfg.norm != "instance":
-        bad.append(f"norm={cfg.norm!r} (only 'instance')")
+    if cfg.norm not in ("instance", "batch", "group"):
+        bad.append(f"norm={cfg.norm!r} (only 'instance'/'batch'/'group')")
     if cfg.downsample not in ("stride", "avgpool", "maxpool"):
         bad.append(f"downsample={cfg.downsample!r}")
     if cfg.upsample not in ("bilinear", "nearest"):
@@ -243,6 +266,11 @@ class PlanBuilder:
         self.stats_scratch = self.new_buf("stats_scratch", (n_sc,), "f32")
         # per-wave partial results of the weight-gradient kernel (36 KB each); see wgrad_slab_parts()
         self.wgrad_slab = self.new_buf("wgrad_slab", (wgrad_slab_parts(cfg) * WG_PART,), "f32")
+        # BatchNorm2d / GroupNorm ride on the InstanceNorm kernels: NORM_COMBINE pools the per-(n,c) statistics
+        self.norm_kind = {"instance": 0, "batch": 1 if training else 3, "group": 2}[cfg.norm]
+        self.nstate_offsets, n_ns = norm_state_layout(cfg)
+        # running statistics: the caller may bind its own tensor (UNet's buffers) before allocate(); else see init_norm_state()
+        self.nstate = self.new_buf("norm_state", (max(n_ns, 8),), "f32")
         self.convs: "OrderedDict[str, dict]" = OrderedDict()
         for k, s in self.shapes.items():
             if len(s) == 4 and s[2] == 3:
@@ -290,6 +318,26 @@ class PlanBuilder:
         off = self.s_slab.shape[0]
         self.s_slab.shape = (off + (n + 63) // 64 * 64,)
         return Ref(self.s_slab, off)
+
+    def init_norm_state(self) -> None:
+        """Fresh BatchNorm2d running statistics (mean 0, variance 1) in a norm-state buffer this plan allocated itself."""
+        self.nstate.tensor.zero_()
+        for k, o in self.nstate_offsets.items():
+            if k.endswith("running_var"):
+                c = self.shapes[k[: -len("running_var")] + "weight"][0]
+                self.nstate.tensor[o:o + c] = 1.0
+
+    def nref(self, name: str) -> Ref:
+        return Ref(self.nstate, self.nstate_offsets[name])
+
+    def e_norm_combine(self, ops, norm: str, st: Buf, C: int, HW: int) -> None:
+        k = self.norm_kind
+        if not k:
+            return
+        run = k in (1, 3)
+        self.op(ops, "NORM_COMBINE", [self.B, C, k, group_size(self.cfg.group_norm_groups, C) if k == 2 else 1, HW], f=[1e-5, 0.1],
+                p=[Ref(st), self.nref(norm + ".running_mean") if run else None, self.nref(norm + ".running_var") if run else None],
+                tag=norm)
 
     def pref(self, name: str) -> Ref:
         return Ref(self.params, self.offsets[name])
@@ -374,7 +422,9 @@ class PlanBuilder:
         u = Unit(conv, norm, xin, raw, st, out, res, drop_site, drop_p)
         fused = self.fused_stats_ok(H, W, c["Cin_pad"], cout)
         self.e_conv(ops, xin, c["Wf"], None, PV(raw, cout), c["Cin_pad"], cout, tag=conv, stats=fused)
-        self.e_stats(ops, PV(raw, cout), st, from_conv=fused)
+        if self.norm_kind != 3:                 # eval-mode BatchNorm2d normalises with the running statistics alone
+            self.e_stats(ops, PV(raw, cout), st, from_conv=fused)
+        self.e_norm_combine(ops, norm, st, cout, H * W)
         self.e_apply(ops, u)
         return u
 
@@ -485,8 +535,15 @@ class PlanBuilder:
             gp, gl, gc, gf = Ref(G), C, 0, 0
         else:
             gp, gl, gc, gf = g1.pv.ref, g1.pv.ldc, g1.pv.coff, g1.fold
-        self.op(ops, "INACT_BWD_APPLY", [B, H, W, C, gl, gc, C, 0, C, 0, self.act, u.drop_site, self.seed, gf, self.pm], f=[u.drop_p],
-                p=[gp, Ref(u.raw), Ref(u.st), self.pref(u.norm + ".weight"), self.pref(u.norm + ".bias"), S, Ref(draw)],
+        Sa = S
+        if self.norm_kind:
+            # BatchNorm2d / GroupNorm: centre with the gamma-weighted mean of S over the normalisation group (S stays for dgamma/dbeta)
+            Sa = self.s_alloc(B * C * 2)
+            self.op(ops, "NORM_COMBINE_BWD", [B, C, self.norm_kind, group_size(self.cfg.group_norm_groups, C) if self.norm_kind == 2 else 1],
+                    p=[S, self.pref(u.norm + ".weight"), Sa], tag=u.norm)
+        self.op(ops, "INACT_BWD_APPLY", [B, H, W, C, gl, gc, C, 0, C, 0, self.act, u.drop_site, self.seed, gf, self.pm,
+                                         1 if self.norm_kind else 0], f=[u.drop_p],
+                p=[gp, Ref(u.raw), Ref(u.st), self.pref(u.norm + ".weight"), self.pref(u.norm + ".bias"), Sa, Ref(draw)],
                 tag=u.conv)
         for s in srcs:                      # only now: in the single-source form pass 2 still reads srcs[0]
             self.release(s.pv.buf)
@@ -683,6 +740,8 @@ def allocate(pb: PlanBuilder, device) -> int:
             continue
         b.tensor = torch.zeros(b.shape, dtype=_torch_dtype(b.kind, pb.dtype), device=device)
         total += b.tensor.numel() * b.tensor.element_size()
+        if b is pb.nstate:
+            pb.init_norm_state()
     return total
 
 

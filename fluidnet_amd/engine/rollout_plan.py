@@ -12,7 +12,8 @@ from .plan import OpRec, PlanBuilder, Ref, allocate, lower
 
 
 class RolloutInferPlan:
-    def __init__(self, cfg, B: int, H: int, W: int, *, params_flat: torch.Tensor, dtype: str = "bf16", conv_impl: str = "auto"):
+    def __init__(self, cfg, B: int, H: int, W: int, *, params_flat: torch.Tensor, dtype: str = "bf16", conv_impl: str = "auto",
+                 norm_state: Optional[torch.Tensor] = None):
         self.B, self.H, self.W = B, H, W
         pb = self.pb = PlanBuilder(cfg, B, H, W, dtype=dtype, conv_impl=conv_impl, training=False)
         HW = H * W
@@ -32,6 +33,9 @@ class RolloutInferPlan:
         self.frame = frame
         pb.params.tensor = params_flat
         pb.grads.tensor = params_flat           # unused by inference ops; bound so that lowering never sees a null buffer
+        if norm_state is not None:              # BatchNorm2d running statistics of the checkpoint (eval mode reads them)
+            assert norm_state.numel() == pb.nstate.numel
+            pb.nstate.tensor = norm_state
         self.bytes = allocate(pb, params_flat.device)
         self._prep = lower(pb, self.prep)
         self._frame = lower(pb, frame)

@@ -23,6 +23,9 @@ class RolloutTrainPlan:
                  clip_norm: Optional[float] = 1.0, betas=(0.9, 0.999), eps: float = 1e-8):
         self.cfg, self.lc, self.B, self.H, self.W, self.K = cfg, lc, B, H, W, K
         self.world = world
+        if world > 1 and cfg.norm == "batch":
+            raise NotImplementedError("BatchNorm2d under data parallelism would normalise with per-rank batch statistics (the reference "
+                                      "has no multi-GPU path to mirror); shard UNet_small runs by experiment, not by batch")
         self.clip_norm = clip_norm
         self.betas, self.eps = betas, eps
         pb = self.pb = PlanBuilder(cfg, B, H, W, dtype=dtype, conv_impl=conv_impl, training=training, seed=seed)
@@ -116,13 +119,16 @@ class RolloutTrainPlan:
             a = self._lowered["opt"][-1]
             a["f"][0], a["f"][4], a["f"][5] = lr, bc1, bc2s
 
-    def bind(self, device, params_flat, grads_flat, adam_m=None, adam_v=None) -> int:
+    def bind(self, device, params_flat, grads_flat, adam_m=None, adam_v=None, norm_state=None) -> int:
         """Allocate all internal buffers on `device` and lower the sections (device must be a GPU for run()).  adam_m / adam_v:
         externally owned Adam moment buffers (so that several plans of different batch shapes share one optimizer state)."""
         self.pb.params.tensor = params_flat
         self.pb.grads.tensor = grads_flat
         if adam_m is not None:
             self.m.tensor, self.v.tensor = adam_m, adam_v
+        if norm_state is not None:             # BatchNorm2d running statistics owned by the caller; else a fresh (0, 1) buffer
+            assert norm_state.numel() == self.pb.nstate.numel
+            self.pb.nstate.tensor = norm_state
         nbytes = allocate(self.pb, device)
         if str(device) != "cpu":
             self._lowered = {k: lower(self.pb, v) for k, v in self.sections.items()}

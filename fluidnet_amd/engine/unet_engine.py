@@ -29,7 +29,7 @@ class _Slot:
 
 class UNetEngine:
     def __init__(self, cfg, B: int, H: int, W: int, *, params_flat: torch.Tensor, grads_flat: torch.Tensor, dtype: str,
-                 conv_impl: str, training: bool, seed: int = 0):
+                 conv_impl: str, training: bool, seed: int = 0, norm_state: Optional[torch.Tensor] = None):
         self.cfg, self.B, self.H, self.W = cfg, B, H, W
         self.training = training
         self.device = params_flat.device
@@ -37,6 +37,9 @@ class UNetEngine:
         assert params_flat.numel() == self.pb.n_params_padded
         self.pb.params.tensor = params_flat
         self.pb.grads.tensor = grads_flat
+        if norm_state is not None:             # BatchNorm2d running statistics owned by the caller (UNet's buffers)
+            assert norm_state.numel() == self.pb.nstate.numel and norm_state.dtype == torch.float32
+            self.pb.nstate.tensor = norm_state
         self.slots: List[_Slot] = []
         self._prep: Optional[np.ndarray] = None
         self._prepped_version = -1

@@ -17,7 +17,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from ..engine.plan import check_supported, unet_param_shapes
+from ..engine.plan import check_supported, norm_state_layout, unet_param_shapes
 from ..engine.unet_engine import UNetEngine
 
 NormType = Literal["none", "batch", "instance", "group"]
@@ -172,6 +172,9 @@ class UNet(nn.Module):
         self._gflat: Optional[torch.Tensor] = None
         self._anchor: Optional[torch.Tensor] = None
         self._offsets: Optional[Dict[str, int]] = None
+        # BatchNorm2d running statistics, flat like the parameters (the engine updates them in place); the modules' buffers are views
+        self._nflat: Optional[torch.Tensor] = None
+        self._noffsets, self._nstate_len = norm_state_layout(self.cfg)
 
     # ------------------------------------------------------------------ flat parameter storage
     def _layout(self):
@@ -199,6 +202,15 @@ class UNet(nn.Module):
                 p.data = flat[o:o + cnt].view(p.shape)
                 p.grad = None
         self._flat, self._gflat, self._offsets = flat, gflat, offsets
+        nflat = torch.zeros(max(self._nstate_len, 8), dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for name, o in self._noffsets.items():
+                mod_name, leaf = name.rsplit(".", 1)
+                mod = self.get_submodule(mod_name)
+                buf = getattr(mod, leaf)
+                nflat[o:o + buf.numel()].copy_(buf.detach().float())
+                setattr(mod, leaf, nflat[o:o + buf.numel()])
+        self._nflat = nflat
         self._anchor = torch.zeros((), device=dev, requires_grad=True)
         self._engines.clear()
 
@@ -208,6 +220,10 @@ class UNet(nn.Module):
         base = self._flat.data_ptr()
         for n, p in self.named_parameters():
             if p.data_ptr() != base + 4 * self._offsets[n] or p.dtype != torch.float32:
+                return False
+        for name, o in self._noffsets.items():
+            mod_name, leaf = name.rsplit(".", 1)
+            if getattr(self.get_submodule(mod_name), leaf).data_ptr() != self._nflat.data_ptr() + 4 * o:
                 return False
         return True
 
@@ -243,9 +259,23 @@ class UNet(nn.Module):
         eng = self._engines.get(key)
         if eng is None:
             eng = UNetEngine(self.cfg, B, H, W, params_flat=self._flat, grads_flat=self._gflat, dtype=self.precision,
-                             conv_impl=self.conv_impl, training=training, seed=self.seed)
+                             conv_impl=self.conv_impl, training=training, seed=self.seed, norm_state=self._nflat)
             self._engines[key] = eng
         return eng
+
+    @property
+    def flat_norm_state(self) -> torch.Tensor:
+        """BatchNorm2d running_mean / running_var of every norm layer in one buffer (plan.norm_state_layout); 8 zeros otherwise."""
+        if not self._is_flat():
+            self._flatten()
+        return self._nflat
+
+    def count_batches(self, n: int = 1) -> None:
+        """BatchNorm2d.num_batches_tracked += n (bookkeeping only: momentum is the fixed 0.1 of unet.py:21)."""
+        if self.cfg.norm == "batch":
+            for m in self.modules():
+                if isinstance(m, nn.BatchNorm2d):
+                    m.num_batches_tracked += n
 
     # ------------------------------------------------------------------ forward
     def forward(self, x: torch.Tensor) -> torch.Tensor:
@@ -259,6 +289,8 @@ class UNet(nn.Module):
         if not self._is_flat():
             self._flatten()
         x = x.contiguous().float()
+        if self.training:
+            self.count_batches(1)
         if not torch.is_grad_enabled():
             out, _ = self._engine(x, training=self.training).forward(x, keep=False)
             return out

@@ -157,7 +157,8 @@ class Trainer:
                                  betas=self.optimizer.betas, eps=self.optimizer.eps, seed=self.model.seed)
             # one Adam state for every shape: the plans share the optimizer's moment buffers
             _, _, m, v, _ = self.optimizer._state()
-            p.bind(self.model.flat_params.device, self.model.flat_params, self.model.flat_grads, adam_m=m, adam_v=v)
+            p.bind(self.model.flat_params.device, self.model.flat_params, self.model.flat_grads, adam_m=m, adam_v=v,
+                   norm_state=self.model.flat_norm_state)
             self._plans[key] = p
         return p
 
@@ -182,6 +183,7 @@ class Trainer:
         plan.set_dropout_seed(self.optimizer.step_count * 7919 + 13)
         world = self._dist.get_world_size() if self._dist is not None else 1
         dp_train_step(plan, world, torch_all_reduce(self._dist) if world > 1 else None)
+        self.model.count_batches(plan.K)        # BatchNorm2d bookkeeping: the plan applied the model K times in training mode
         self.model.flat_params.add_(0)          # bump the autograd version: autograd-path engines refresh their bf16 weights
         return plan.loss_dict()
 

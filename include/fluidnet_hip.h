@@ -113,6 +113,8 @@ enum FnetOpCode {
     FNET_OP_GATHER_BATCH = 31,
     FNET_OP_POOL2X = 32,          /* 2x2 average / max pooling of the pooled `down` variants (unet.py:93-94) */
     FNET_OP_POOL2X_BWD = 33,
+    FNET_OP_NORM_COMBINE = 34,    /* BatchNorm2d / GroupNorm statistics pooled from the per-(n,c) ones (unet.py:20-28) */
+    FNET_OP_NORM_COMBINE_BWD = 35,
     FNET_OP_COUNT_
 };
 
@@ -171,9 +173,11 @@ int fnet_timer_destroy(void* timer);
 /*
  * Native inference rollout: the per-step work of the reference's C++ viewer
  * (engine/src/Simulation.cpp:236-367: pack six planes, Ort::Session::Run, copy the output into
- * the back buffer) as one device-resident loop.  Model family: norm = instance, downsample =
- * stride (UNet_medium's); weights = the trainable tensors of a reference checkpoint in
- * state-dict order (ml/models/unet.py:204-279), concatenated as fp32; bf16 MFMA arithmetic.
+ * the back buffer) as one device-resident loop.  Model family: the four shipped architectures' block
+ * types (instance / batch / group norm, stride or pooled downsample, nearest or bilinear upsample);
+ * weights = the float tensors of a reference checkpoint in state-dict order (ml/models/unet.py:204-279;
+ * BatchNorm2d: weight, bias, running_mean, running_var -- not its int64 counter), concatenated as fp32;
+ * bf16 MFMA arithmetic.
  *   fnet_unet_param_count   number of floats fnet_rollout_create expects for a configuration
  *   fnet_rollout_create     allocates every device buffer (hipMalloc), uploads and re-lays the weights,
  *                           captures one frame in a hipGraph; synchronises
@@ -194,6 +198,9 @@ typedef struct FnetUNetConfig {
     int32_t use_residual;       /* 0 / 1 */
     int32_t bottleneck_blocks;
     int32_t output_activation;  /* FNET_OUT_* */
+    int32_t norm;               /* 0 instance, 1 batch (eval mode: running statistics), 2 group */
+    int32_t downsample;         /* 0 stride-2 conv, 1 avgpool + conv, 2 maxpool + conv */
+    int32_t group_norm_groups;  /* norm == 2: the reference's `groups` (largest divisor of the channel count <= it is used) */
 } FnetUNetConfig;
 int fnet_unet_param_count(const FnetUNetConfig* cfg, int64_t* n_floats);
 int fnet_rollout_create(const FnetUNetConfig* cfg, const float* host_params, int64_t n_params, int32_t B, int32_t H, int32_t W,

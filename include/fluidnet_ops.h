@@ -73,8 +73,17 @@
  * INACT_BWD_APPLY   <- pass 2: gradient w.r.t. the conv output
  *   i: 0 B, 1 H, 2 W, 3 C, 4 ldc_G, 5 coff_G, 6 ldc_raw, 7 coff_raw, 8 ldc_d, 9 coff_d, 10 act, 11 dropout site, 12 seed,
  *      13 fold (1 = p[0] is an unfolded gradient source: its ring is folded onto the interior here, rounded to the
- *      element type exactly as pass 1 would have stored it in G), 14 pm (used when fold = 1)
+ *      element type exactly as pass 1 would have stored it in G), 14 pm (used when fold = 1),
+ *      15 weighted S (1: p[5] is NORM_COMBINE_BWD's output, BatchNorm2d / GroupNorm)
  *   f: 0 drop_p; p: 0 G (or the single source g1), 1 raw, 2 stats, 3 gamma, 4 beta, 5 S, 6 d_raw out P (ring = 0)
+ * NORM_COMBINE      <- BatchNorm2d / GroupNorm (unet.py:20-28) on top of IN_STATS: pools the per-(n,c) (mean, rstd) over the batch
+ *                      (kind 1, training; also updates the running statistics: momentum f[1], unbiased variance) or over the
+ *                      channels of a group (kind 2), in place, every (n,c) receiving its pool's values; kind 3 = eval-mode
+ *                      BatchNorm2d: statistics = the running ones (no IN_STATS needed)
+ *                   i: 0 B, 1 C, 2 kind, 3 channels per group (kind 2), 4 H*W; f: 0 eps, 1 momentum
+ *                   p: 0 stats float2[B][C], 1 running_mean|0, 2 running_var|0
+ * NORM_COMBINE_BWD  i: 0 B, 1 C, 2 kind, 3 channels per group; p: 0 S float2[B][C], 1 gamma, 2 Sw float2[B][C] out: the
+ *                      gamma-weighted mean of S over the normalisation group (kind 3: zeros), read by INACT_BWD_APPLY with i[15] = 1
  * AFFINE_GRAD       i: 0 B, 1 C; p: 0 S float2[B][C], 1 dgamma (+=), 2 dbeta (+=)
  * AFFINE_GRAD_MULTI AFFINE_GRAD of up to 7 norm layers in one launch (the plan batches a backward pass's 26 layers into 4)
  *   i: 0 B, 1 n_units (<= 7), then per unit u at 2+4u: S offset (floats from p[0]), C, dgamma offset, dbeta offset (floats from p[1])

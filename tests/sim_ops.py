@@ -228,10 +228,54 @@ class Sim:
         dz = g * self._drop(B, C, site, seed, r.f[0]) * act_bwd(u, act)
         S = self.flat(r.p[5])[: B * C * 2].view(B, C, 2)
         inv = 1.0 / (H * W)
-        d = gamma * stats[:, None, None, :, 1] * (dz - S[:, None, None, :, 0] * inv - xh * S[:, None, None, :, 1] * inv)
+        rstd = stats[:, None, None, :, 1]
+        if len(r.i) > 15 and r.i[15]:                           # S = NORM_COMBINE_BWD's gamma-weighted group means
+            d = gamma * rstd * dz - rstd * (S[:, None, None, :, 0] * inv + xh * S[:, None, None, :, 1] * inv)
+        else:
+            d = gamma * rstd * (dz - S[:, None, None, :, 0] * inv - xh * S[:, None, None, :, 1] * inv)
         out = torch.zeros(B, H + 2, W + 2, C)
         out[:, 1:-1, 1:-1] = d
         self.wr(r.p[6], C, ld, cd, out)
+
+    def op_NORM_COMBINE(self, r):
+        B, C, kind, gs, HW = r.i[:5]
+        eps, mom = r.f[0], r.f[1]
+        st = r.p[0].buf.tensor.view(-1)[r.p[0].off: r.p[0].off + B * C * 2].view(B, C, 2)
+        if kind == 3:
+            st[:, :, 0] = self.flat(r.p[1])[:C]
+            st[:, :, 1] = torch.rsqrt(self.flat(r.p[2])[:C] + eps)
+            return
+        mean = st[:, :, 0].clone()
+        e2 = (1.0 / st[:, :, 1] ** 2 - eps).clamp_min(0) + mean ** 2
+        if kind == 1:
+            m, q = mean.mean(0), e2.mean(0)
+            var = (q - m * m).clamp_min(0)
+            st[:, :, 0] = m
+            st[:, :, 1] = torch.rsqrt(var + eps)
+            if r.p[1] is not None:
+                n = float(B * HW)
+                rm, rv = self.flat(r.p[1]), self.flat(r.p[2])
+                rm[:C] = (1 - mom) * rm[:C] + mom * m
+                rv[:C] = (1 - mom) * rv[:C] + mom * var * (n / max(n - 1.0, 1.0))
+        else:
+            m = mean.view(B, C // gs, gs).mean(2, keepdim=True)
+            q = e2.view(B, C // gs, gs).mean(2, keepdim=True)
+            var = (q - m * m).clamp_min(0)
+            st[:, :, 0] = m.expand(B, C // gs, gs).reshape(B, C)
+            st[:, :, 1] = torch.rsqrt(var + eps).expand(B, C // gs, gs).reshape(B, C)
+
+    def op_NORM_COMBINE_BWD(self, r):
+        B, C, kind, gs = r.i[:4]
+        S = self.flat(r.p[0])[: B * C * 2].view(B, C, 2)
+        gamma = self.flat(r.p[1])[:C]
+        out = self.flat(r.p[2])[: B * C * 2].view(B, C, 2)
+        if kind == 1:
+            out.copy_((gamma[:, None] * S.mean(0)).expand(B, C, 2))
+        elif kind == 2:
+            w = (gamma[None, :, None] * S).view(B, C // gs, gs, 2).mean(2, keepdim=True)
+            out.copy_(w.expand(B, C // gs, gs, 2).reshape(B, C, 2))
+        else:
+            out.zero_()
 
     def op_AFFINE_GRAD(self, r):
         B, C = r.i[:2]

@@ -27,7 +27,7 @@ DEV = "cuda"
 
 def _model(cfg, params, precision, conv_impl="auto", train=True):
     m = UNet(UNetConfig(**cfg.__dict__), precision=precision, conv_impl=conv_impl)
-    m.load_state_dict(params, strict=True)
+    m.load_state_dict(params, strict=cfg.norm != "batch")      # the seeded parameter set has no BatchNorm2d buffers
     m.to(DEV)
     m.train(train)
     return m
@@ -151,6 +151,7 @@ ARCHS = {
     "medium": (dict(), 128),
     "large": (dict(base_channels=48, depth=4, downsample="avgpool"), 64),        # UNet_large.yaml
     "medium-maxpool": (dict(base_channels=16, downsample="maxpool"), 64),
+    "small": (dict(base_channels=16, depth=2, norm="batch", upsample="nearest", downsample="avgpool", padding_mode="zeros"), 128),  # UNet_small.yaml
 }
 
 
@@ -204,7 +205,7 @@ def test_eval_mode_and_no_grad_and_cpu_rejection():
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         m(torch.from_numpy(x0))
     with pytest.raises(NotImplementedError):
-        UNet(UNetConfig(in_channels=6, norm="batch", base_channels=16)).to(DEV)(torch.from_numpy(x0).to(DEV))
+        UNet(UNetConfig(in_channels=6, norm="none", base_channels=16)).to(DEV)(torch.from_numpy(x0).to(DEV))
     with pytest.raises(ValueError, match="depth must be >= 1"):
         UNet(UNetConfig(depth=0))
 
@@ -225,3 +226,46 @@ def test_dropout_training_matches_oracle_with_injected_masks():
     assert (out.detach().cpu() - ref).abs().max() < 1e-4
     frac = np.mean([float((v == 0).float().mean()) for v in dm.values()])
     assert 0.1 < frac < 0.4
+
+
+def test_batch_norm_module_train_eval_and_state_dict():
+    """UNet_small's family through the nn.Module API (fp32 path): training-mode forward/backward with BatchNorm2d batch statistics,
+    the running statistics it leaves in the module's buffers (state-dict keys of nn.BatchNorm2d), then eval mode on those."""
+    cfg = tiny_cfg(norm="batch", downsample="avgpool", upsample="nearest", padding_mode="zeros", base_channels=16)
+    params = orc.make_params(cfg, seed=21)
+    m = _model(cfg, params, "fp32")
+    sd_keys = set(m.state_dict().keys())
+    assert {"downs.0.block.n1.running_mean", "downs.0.block.n1.running_var", "downs.0.block.n1.num_batches_tracked"} <= sd_keys
+    x0, y, _ = orc.synth_batch(3, 1, 32, seed=77)
+    x = torch.from_numpy(x0).to(DEV)
+    bn = {}
+    for k, v in m.state_dict().items():
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            bn[k] = v.detach().cpu().clone()
+    crit = _crit(loss_c2(32, padding_mode="zeros"))
+    for step in range(2):                                  # two training-mode forwards: statistics accumulate
+        out = m(x)
+        loss, _ = crit(out, torch.from_numpy(y[:, 0]).to(DEV), x)
+        m.zero_grad()
+        loss.backward()
+        p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+        oout = orc.unet_forward(p, cfg, torch.from_numpy(x0), training=True, bn_state=bn)
+        oloss, _ = orc.physics_loss(oout, torch.from_numpy(y[:, 0]), torch.from_numpy(x0), loss_c2(32, padding_mode="zeros"))
+        oloss.backward()
+        assert (out.detach().cpu() - oout.detach()).abs().max() < 2e-4
+        worst = max(relerr(v.grad, p[k].grad) for k, v in m.named_parameters())
+        assert worst < 2e-4, worst
+    sd = m.state_dict()
+    for k, v in bn.items():
+        assert (sd[k].cpu() - v).abs().max() < 1e-5 * max(1.0, float(v.abs().max())), k
+    assert int(sd["mid.0.b.n2.num_batches_tracked"]) == 2
+    m.eval()
+    with torch.no_grad():
+        e = m(x)
+    eref = orc.unet_forward(params, cfg, torch.from_numpy(x0), training=False, bn_state=bn)
+    assert (e.cpu() - eref).abs().max() < 2e-4
+    # a reference-format checkpoint round trip keeps the statistics (buffers stay views of the flat norm state)
+    m2 = _model(cfg, orc.make_params(cfg, seed=5), "fp32", train=False)
+    m2.load_state_dict(sd)
+    with torch.no_grad():
+        assert torch.equal(m2(x), e)

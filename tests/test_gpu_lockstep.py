@@ -37,6 +37,10 @@ CASES = [
     ("fp32-ref-avgpool", dict(downsample="avgpool"), "replicate", "fp32", "ref", 8),
     ("bf16-mfma-maxpool-reflect", dict(downsample="maxpool", dropout=0.1), "reflect", "bf16", "mfma", 16),
     ("bf16-mfma-avgpool-depth3", dict(downsample="avgpool", depth=3), "zeros", "bf16", "mfma", 16),
+    ("fp32-ref-batchnorm-small", dict(norm="batch", downsample="avgpool", upsample="nearest"), "zeros", "fp32", "ref", 8),
+    ("bf16-mfma-batchnorm-small", dict(norm="batch", downsample="avgpool", upsample="nearest", dropout=0.1), "zeros", "bf16", "mfma", 16),
+    ("fp32-ref-groupnorm", dict(norm="group", act="silu", use_residual=False), "zeros", "fp32", "ref", 8),
+    ("bf16-mfma-groupnorm", dict(norm="group", act="silu", group_norm_groups=4), "replicate", "bf16", "mfma", 16),
 ]
 
 

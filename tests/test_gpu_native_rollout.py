@@ -6,7 +6,7 @@ import pytest
 import torch
 
 import fluidnet_oracle as orc
-from fluidnet_amd.engine.native_rollout import NativeRollout
+from fluidnet_amd.engine.native_rollout import NativeRollout, checkpoint_floats
 from fluidnet_amd.engine.rollout_plan import RolloutInferPlan
 from fluidnet_amd.engine.runtime import FluidNetHipError
 from fluidnet_amd.models.unet import UNet, UNetConfig
@@ -24,16 +24,28 @@ def _weights(cfg, seed):
     ("tiny", tiny_cfg(), 2, 32),
     ("tiny-noresid-nearest-zeros", tiny_cfg(use_residual=False, upsample="nearest", padding_mode="zeros", act="silu"), 1, 16),
     ("medium", orc.medium_config(dropout=0.0), 3, 64),
+    # the other shipped architectures' block types (ml/config/model_architectures/): UNet_small, UNet_large, and UNetConfig's defaults
+    ("small-batchnorm-avgpool", orc.medium_config(dropout=0.0, base_channels=16, depth=2, norm="batch", upsample="nearest",
+                                                  downsample="avgpool", padding_mode="zeros"), 2, 64),
+    ("large-avgpool", orc.medium_config(dropout=0.0, base_channels=48, depth=4, downsample="avgpool"), 1, 64),
+    ("groupnorm-maxpool", tiny_cfg(norm="group", act="silu", downsample="maxpool", base_channels=16, group_norm_groups=4), 2, 32),
 ])
 def test_native_rollout_equals_python_plan(name, cfg, B, R):
     params, flat = _weights(cfg, seed=3)
     model = UNet(UNetConfig(**cfg.__dict__), precision="bf16")
-    model.load_state_dict(params)
+    model.load_state_dict(params, strict=cfg.norm != "batch")
+    if cfg.norm == "batch":                    # a trained checkpoint's running statistics: anything but (0, 1)
+        g = torch.Generator().manual_seed(5)
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.copy_(0.1 * torch.randn(m.running_mean.shape, generator=g))
+                m.running_var.copy_(1.0 + 0.3 * torch.rand(m.running_var.shape, generator=g))
     model = model.cuda().eval()
+    flat = checkpoint_floats(model.state_dict())
     em, co = orc.simple_infer_masks(R, scale=R / 128.0)
     e = np.repeat(em[None], B, 0).astype(np.float32)
     c = np.repeat(co[None], B, 0).astype(np.float32)
-    plan = RolloutInferPlan(model.cfg, B, R, R, params_flat=model.flat_params)
+    plan = RolloutInferPlan(model.cfg, B, R, R, params_flat=model.flat_params, norm_state=model.flat_norm_state)
     plan.reset(torch.from_numpy(e).cuda(), torch.from_numpy(c).cuda())
     nat = NativeRollout(model.cfg, flat, B, R, R)
     nat.set_masks(e, c)
@@ -66,7 +78,7 @@ def test_native_rollout_rejects_bad_arguments():
     with pytest.raises(FluidNetHipError):
         NativeRollout(mcfg, flat, 1, 30, 32)            # not divisible by 2^depth
     with pytest.raises(NotImplementedError):
-        NativeRollout(UNetConfig(**tiny_cfg(norm="batch").__dict__), flat, 1, 32, 32)
+        NativeRollout(UNetConfig(**tiny_cfg(norm="none").__dict__), flat, 1, 32, 32)
     nat = NativeRollout(mcfg, flat, 1, 32, 32)
     with pytest.raises(ValueError):
         nat.set_masks(np.zeros((2, 32, 32), np.float32), None)

@@ -107,6 +107,48 @@ def test_train_loop_checkpoint_and_backend(tmp_path):
     assert tr.load_checkpoint(tr.config.checkpoint_dir / "checkpoint_epoch_1.pth") == 0
 
 
+def test_unet_small_family_batch_norm_training(tmp_path):
+    """UNet_small's block types (BatchNorm2d, avgpool, nearest, zeros padding; UNet_small.yaml) through the Trainer: the native K-step
+    plan and the autograd engine take the same two steps, leave the same running statistics and batch counters in the state dict,
+    and the checkpoint serves eval-mode inference through the backend."""
+    root = _npz(tmp_path)
+    K = 2
+    cfgT = _config(tmp_path, K).model_copy(update=dict(norm="batch", downsample="avgpool", upsample="nearest", padding_mode="zeros"))
+    ds = FluidNPZSequenceDataset(root, "train", rollout_steps=K, preload=True, stride=1)
+    batches = [next(iter(DataLoader(ds, batch_size=2, shuffle=False)))]
+    cfg = tiny_cfg(norm="batch", downsample="avgpool", upsample="nearest", padding_mode="zeros")
+    outs = {}
+    for engine in ("plan", "autograd"):
+        m = UNet(UNetConfig(**cfg.__dict__), precision="fp32")
+        m.load_state_dict(orc.make_params(cfg, seed=4), strict=False)
+        m.to("cuda")
+        tr = Trainer(m, batches, batches, cfgT, "cuda", engine=engine)
+        d1, d2 = tr.train_epoch(), tr.train_epoch()
+        outs[engine] = (d1, d2, {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}, tr, m)
+    sp, sa = outs["plan"][2], outs["autograd"][2]
+    assert abs(outs["plan"][0]["total"] - outs["autograd"][0]["total"]) < 2e-5
+    for k in sp:
+        if k.endswith("num_batches_tracked"):
+            assert int(sp[k]) == int(sa[k]) == 2 * K, k
+        elif "running_" in k:
+            assert (sp[k] - sa[k]).abs().max() < 1e-4 * max(1.0, float(sa[k].abs().max())), k
+            assert (sp[k] - (1.0 if k.endswith("var") else 0.0)).abs().max() > 1e-4, k       # really updated
+        else:
+            assert (sp[k] - sa[k]).abs().max() < 2e-3, k
+    tr, m = outs["plan"][3], outs["plan"][4]
+    tr.save_checkpoint(0)
+    be = PyTorchBackend(precision="fp32")
+    be.load_model(tr.config.checkpoint_dir / "checkpoint_epoch_1.pth", "cuda")
+    x = np.random.RandomState(0).rand(1, 6, 32, 32).astype(np.float32)
+    with torch.no_grad():
+        ref = m.eval()(torch.from_numpy(x).cuda()).cpu().numpy()
+    np.testing.assert_allclose(be.infer(x), ref, atol=1e-6)
+    p = {k: v for k, v in sp.items() if k in orc.param_shapes(cfg)}
+    bn = {k: v for k, v in sp.items() if "running_" in k}
+    oref = orc.unet_forward(p, cfg, torch.from_numpy(x), training=False, bn_state=bn)
+    assert float((torch.from_numpy(ref) - oref).abs().max()) < 2e-4
+
+
 def test_hbm_loader_epoch_equals_dataloader_epoch(tmp_path):
     """Trainer fed by the HBM-resident loader (one gather kernel per batch into the plan's buffers) takes the same steps as
     Trainer fed the same samples as host batches."""

@@ -34,9 +34,20 @@ def run_case(cfg, lc, B, R, K, *, trunc=False, fin=False, seed=5, dropout_seed=0
     dm = None
     if cfg.dropout > 0:
         dm = [drop_masks_for(cfg, B, dropout_seed, k, cfg.dropout) for k in range(K)]
+    bn = None
+    if cfg.norm == "batch":                     # fresh BatchNorm2d buffers; the K applications update them in turn
+        bn = {}
+        for k_ in pb.nstate_offsets:
+            c = params[k_.rsplit(".", 1)[0] + ".weight"].numel()
+            bn[k_] = torch.ones(c) if k_.endswith("running_var") else torch.zeros(c)
     loss, d, pred = orc.rollout_loss(p, cfg, lc, torch.from_numpy(x0), torch.from_numpy(y), torch.from_numpy(mk),
-                                     weight_decay=1.10, gradient_truncation=trunc, final_step_only=fin, training=True, drop_masks=dm)
+                                     weight_decay=1.10, gradient_truncation=trunc, final_step_only=fin, training=True, drop_masks=dm,
+                                     bn_state=bn)
     loss.backward()
+    if bn is not None:
+        for k_, o in pb.nstate_offsets.items():
+            got_rs = pb.nstate.tensor[o:o + bn[k_].numel()]
+            assert (got_rs - bn[k_]).abs().max() < 1e-5 * max(1.0, float(bn[k_].abs().max())), k_
     got = plan.loss_dict()
     assert abs(got["total"] - float(loss.detach())) < 2e-6 * max(1, abs(float(loss.detach())))
     for k_, v in d.items():
@@ -92,6 +103,20 @@ def test_pooled_downsample(mode, pm):
     """Sequential(pool, conv3x3) `down` of UNet_small / UNet_small-medium / UNet_large (unet.py:93-94)"""
     # K = 1 for max: the argmax is discontinuous, a second application amplifies fp32 noise past the K <= 2 gradient bar
     run_case(tiny_cfg(downsample=mode, padding_mode=pm), loss_c2(16, padding_mode=pm), 2, 16, 2 if mode == "avgpool" else 1)
+
+
+def test_batch_norm_small_architecture():
+    """UNet_small's block types (UNet_small.yaml): BatchNorm2d in training mode incl. running statistics, avgpool, nearest, zeros"""
+    run_case(tiny_cfg(norm="batch", downsample="avgpool", upsample="nearest", padding_mode="zeros"),
+             loss_c2(16, padding_mode="zeros"), 3, 16, 2)
+
+
+def test_group_norm_default_config_blocks():
+    """UNetConfig's own defaults (unet.py:183-201): GroupNorm, SiLU, nearest, zeros, no residual; 16 channels in 8 groups and
+    (base 24, group_norm_groups 5) 48 channels, where the reference's group search settles on 4 groups of 12"""
+    run_case(tiny_cfg(norm="group", act="silu", upsample="nearest", padding_mode="zeros", use_residual=False),
+             loss_c2(16, padding_mode="zeros"), 2, 16, 2)
+    run_case(tiny_cfg(norm="group", base_channels=24, depth=1, group_norm_groups=5), loss_c2(16), 2, 16, 1)
 
 
 def test_dropout_hash_matches_injected_masks():

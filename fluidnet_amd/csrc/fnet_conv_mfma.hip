@@ -93,13 +93,15 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_conv3x3_dma(const 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const int nst = Cin / KC;
+    // Cin need only be a multiple of 8: the last 16-channel stage then runs 8 channels into the next pixel (or past the window,
+    // which reads 0); PREP_WEIGHTS zero-pads the K axis of the weights to the same 16, so those products vanish (finite data)
+    const int nst = (Cin + KC - 1) / KC;
 
     // XCD-aware tile order: work items with equal L % 8 run on blocks that share an L2 (gridDim.x is a multiple of 8); give
     // each XCD a contiguous range of pixel tiles and run the cout tiles of one pixel tile back to back on it.
     const int cpx = (n_mtiles + 7) >> 3;
     const int n_items = 8 * cpx * n_ntiles;
-    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)Wk, 0, 9 * Cout * Cin * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)Wk, 0, 9 * Cout * nst * KC * 2, 0x00020000);
     const int swz = (lane >> 4) & 1;                // bit 3 of the row a DMA lane fills (row = 32*piece + lane/2)
     const int dh = (lane & 1) ^ swz;                // channel half this lane fetches
     const int in_piece_stride = 32 * ldc_in * 2;
@@ -652,7 +654,7 @@ int set_lds_limit(K kernel, size_t bytes) {
 int fnet_conv3x3_mfma(const FnetOp& op, hipStream_t st) {
     const int Npix = op.i[0], Wp = op.i[1], Cin = op.i[2], Cout = op.i[5];
     FNET_CHECK_ARG(op.dtype == FNET_BF16);
-    FNET_CHECK_ARG(Npix > 0 && Wp >= 3 && Cin % KC == 0 && Cout % 8 == 0 && Cout > 0);
+    FNET_CHECK_ARG(Npix > 0 && Wp >= 3 && Cin % 8 == 0 && Cin > 0 && Cout % 8 == 0 && Cout > 0);
     FNET_CHECK_ARG(op.i[3] % 8 == 0 && op.i[4] % 8 == 0 && op.i[6] % 8 == 0 && op.i[7] % 8 == 0);
     FNET_CHECK_ARG(op.i[4] + Cin <= op.i[3] && op.i[7] + Cout <= op.i[6]);
     FNET_CHECK_ARG(op.p[0] && op.p[1] && op.p[3] && (op.p[0] % 16) == 0 && (op.p[1] % 16) == 0 && (op.p[3] % 16) == 0);

@@ -277,7 +277,7 @@ __global__ __launch_bounds__(256) void k_in_finalize_tiles(const float2* part, f
 // channels of a group (GroupNorm, unet.py:24-28).  kind 3 = BatchNorm2d in eval mode: statistics are the running ones.
 // The pooled (mean, rstd) is written back to every (n, c) it covers, so APPLY and the adjoint kernels are unchanged.
 __global__ __launch_bounds__(256) void k_norm_combine(float2* st, float* rmean, float* rvar, int B, int C, int kind, int gs, float eps,
-                                                      float momentum, float count) {
+                                                      float momentum, float count, int Cr /* real channels: groups cover [0, Cr) */) {
     const int i = blockIdx.x * kThreads + threadIdx.x;
     if (kind == 1) {
         if (i >= C) return;
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(256) void k_norm_combine(float2* st, float* rmean, 
             rvar[i] = (1.f - momentum) * rvar[i] + momentum * var * (count / fmaxf(count - 1.f, 1.f));
         }
     } else if (kind == 2) {
-        const int ng = C / gs;
+        const int ng = Cr / gs;
         if (i >= B * ng) return;
         const int n = i / ng, g = i - n * ng;
         float2* s = st + (size_t)n * C + g * gs;
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256) void k_norm_combine(float2* st, float* rmean, 
 // adjoint side: Sw[n][c] = the gamma-weighted mean of S = (sum dz, sum dz*xhat) over the normalisation group of (n, c):
 // kind 1 gamma_c * mean_n S[n][c]; kind 2 mean over the group's channels c' of gamma_c' S[n][c']; kind 3 zero (eval-mode
 // BatchNorm2d is an affine map: nothing to centre).  S itself stays per (n, c) for AFFINE_GRAD.
-__global__ __launch_bounds__(256) void k_norm_combine_bwd(const float2* S, const float* gamma, float2* Sw, int B, int C, int kind, int gs) {
+__global__ __launch_bounds__(256) void k_norm_combine_bwd(const float2* S, const float* gamma, float2* Sw, int B, int C, int kind, int gs, int Cr) {
     const int i = blockIdx.x * kThreads + threadIdx.x;
     if (kind == 1) {
         if (i >= C) return;
@@ -328,8 +328,12 @@ __global__ __launch_bounds__(256) void k_norm_combine_bwd(const float2* S, const
         const float2 o = make_float2(a * g, b * g);
         for (int n = 0; n < B; ++n) Sw[(size_t)n * C + i] = o;
     } else if (kind == 2) {
-        const int ng = C / gs;
-        if (i >= B * ng) return;
+        const int ng = Cr / gs, npad = C - Cr;
+        if (i >= B * ng) {                       // zero-padded channels: nothing to centre
+            const int j = i - B * ng;
+            if (j < B * npad) Sw[(size_t)(j / npad) * C + Cr + j % npad] = make_float2(0.f, 0.f);
+            return;
+        }
         const int n = i / ng, g = i - n * ng;
         float a = 0.f, b = 0.f;
         for (int c = 0; c < gs; ++c) { const float2 v = S[(size_t)n * C + g * gs + c]; const float w = gamma[g * gs + c]; a += w * v.x; b += w * v.y; }
@@ -1125,30 +1129,30 @@ int fnet_op_inact_bwd_apply(const FnetOp& op, hipStream_t st) {
     return FNET_OK;
 }
 
-// NORM_COMBINE  i: 0 B,1 C,2 kind (1 batch/training, 2 group, 3 batch/eval),3 channels per group (kind 2),4 H*W
+// NORM_COMBINE  i: 0 B,1 C,2 kind (1 batch/training, 2 group, 3 batch/eval),3 channels per group (kind 2),4 H*W,5 real C (0 = C)
 //               f: 0 eps,1 momentum; p: 0 stats float2[B][C] (in place),1 running_mean|0,2 running_var|0 (kind 1: updated when given;
 //               kind 3: read)
 int fnet_op_norm_combine(const FnetOp& op, hipStream_t st) {
-    const int B = op.i[0], C = op.i[1], kind = op.i[2], gs = op.i[3];
-    FNET_CHECK_ARG(B > 0 && C > 0 && kind >= 1 && kind <= 3 && op.p[0] && op.i[4] > 0);
-    FNET_CHECK_ARG(kind != 2 || (gs >= 1 && C % gs == 0));
+    const int B = op.i[0], C = op.i[1], kind = op.i[2], gs = op.i[3], Cr = op.i[5] ? op.i[5] : C;
+    FNET_CHECK_ARG(B > 0 && C > 0 && kind >= 1 && kind <= 3 && op.p[0] && op.i[4] > 0 && Cr >= 1 && Cr <= C);
+    FNET_CHECK_ARG(kind != 2 || (gs >= 1 && Cr % gs == 0));
     FNET_CHECK_ARG(kind != 3 || (op.p[1] && op.p[2]));
     FNET_CHECK_ARG((op.p[1] == 0) == (op.p[2] == 0));
-    const int items = kind == 1 ? C : kind == 2 ? B * (C / gs) : B * C;
+    const int items = kind == 1 ? C : kind == 2 ? B * (Cr / gs) : B * C;
     hipLaunchKernelGGL(k_norm_combine, dim3((items + kThreads - 1) / kThreads), dim3(kThreads), 0, st, (float2*)op.p[0], (float*)op.p[1],
-                       (float*)op.p[2], B, C, kind, gs, op.f[0], op.f[1], (float)B * (float)op.i[4]);
+                       (float*)op.p[2], B, C, kind, gs, op.f[0], op.f[1], (float)B * (float)op.i[4], Cr);
     FNET_LAUNCH_CHECK();
     return FNET_OK;
 }
 
-// NORM_COMBINE_BWD  i: 0 B,1 C,2 kind,3 channels per group; p: 0 S float2[B][C],1 gamma,2 Sw float2[B][C] out
+// NORM_COMBINE_BWD  i: 0 B,1 C,2 kind,3 channels per group,4 real C (0 = C); p: 0 S float2[B][C],1 gamma,2 Sw float2[B][C] out
 int fnet_op_norm_combine_bwd(const FnetOp& op, hipStream_t st) {
-    const int B = op.i[0], C = op.i[1], kind = op.i[2], gs = op.i[3];
-    FNET_CHECK_ARG(B > 0 && C > 0 && kind >= 1 && kind <= 3 && op.p[0] && op.p[1] && op.p[2]);
-    FNET_CHECK_ARG(kind != 2 || (gs >= 1 && C % gs == 0));
-    const int items = kind == 1 ? C : kind == 2 ? B * (C / gs) : B * C;
+    const int B = op.i[0], C = op.i[1], kind = op.i[2], gs = op.i[3], Cr = op.i[4] ? op.i[4] : C;
+    FNET_CHECK_ARG(B > 0 && C > 0 && kind >= 1 && kind <= 3 && op.p[0] && op.p[1] && op.p[2] && Cr >= 1 && Cr <= C);
+    FNET_CHECK_ARG(kind != 2 || (gs >= 1 && Cr % gs == 0));
+    const int items = kind == 1 ? C : kind == 2 ? B * (Cr / gs) + B * (C - Cr) : B * C;
     hipLaunchKernelGGL(k_norm_combine_bwd, dim3((items + kThreads - 1) / kThreads), dim3(kThreads), 0, st, (const float2*)op.p[0],
-                       (const float*)op.p[1], (float2*)op.p[2], B, C, kind, gs);
+                       (const float*)op.p[1], (float2*)op.p[2], B, C, kind, gs, Cr);
     FNET_LAUNCH_CHECK();
     return FNET_OK;
 }

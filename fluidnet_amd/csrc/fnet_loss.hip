@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256) void k_head_fwd(const T* src, const float* Wh,
         for (int o = 0; o < MAXO; ++o)
             if (o < Cout) {
 #pragma unroll
-                for (int k = 0; k < 8; ++k) acc[o] += v.v[k] * sw[o * C + c0 + k];
+                for (int k = 0; k < 8; ++k) acc[o] += (c0 + k < C) ? v.v[k] * sw[o * C + c0 + k] : 0.f;   // C % 8 != 0: zero-padded tail
             }
     }
 #pragma unroll
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256) void k_head_fwd(const T* src, const float* Wh,
 template <typename T, int MAXO, int MAXC>
 __global__ __launch_bounds__(256) void k_head_bwd(const float* dpred, const float* z, const float* pred, const T* act, const float* Wh, T* dact,
                            float* dWh, float* dbh, int B, int H, int W, int C, int ldc, int coff, int ldc_d, int coff_d, int Cout,
-                           int outact) {
+                           int outact, int Cz /* channels of dact written: C rounded up to the plan's channel padding */) {
     extern __shared__ float sw[];  // [Cout][C] weights, then [4 waves][Cout*C + Cout] reduction scratch
     for (int i = threadIdx.x; i < Cout * C; i += kThreads) sw[i] = Wh[i];
     __syncthreads();
@@ -283,15 +283,20 @@ __global__ __launch_bounds__(256) void k_head_bwd(const float* dpred, const floa
         const size_t pix = ((size_t)n * (H + 2) + y + 1) * (W + 2) + x + 1;
 #pragma unroll
         for (int cg = 0; cg < MAXC / 8; ++cg) {
-            if (cg * 8 < C) {
+            if (cg * 8 < Cz) {
                 Vec8<T> v, d;
-                v.load(act + pix * ldc + coff + cg * 8);
+                if (cg * 8 < C) v.load(act + pix * ldc + coff + cg * 8);
+                else {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v.v[k] = 0.f;
+                }
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     float acc = 0.f;
+                    const bool real = cg * 8 + k < C;       // zero-padded tail channels get a zero gradient (they must stay zero)
 #pragma unroll
                     for (int o = 0; o < MAXO; ++o)
-                        if (o < Cout) {
+                        if (o < Cout && real) {
                             acc += sw[o * C + cg * 8 + k] * dz[o];
                             gw[o][cg * 8 + k] += dz[o] * v.v[k];
                         }
@@ -525,8 +530,9 @@ int fnet_op_stencil(const FnetOp& op, hipStream_t st) {
 // HEAD_FWD  i: 0 B,1 H,2 W,3 C,4 ldc,5 coff,6 Cout,7 outact; p: 0 src (P),1 Wh fp32 [Cout][C],2 bh,3 z [B,Cout,H,W],4 pred
 int fnet_op_head_fwd(const FnetOp& op, hipStream_t st) {
     const int B = op.i[0], H = op.i[1], W = op.i[2], C = op.i[3], Cout = op.i[6];
-    FNET_CHECK_ARG(B > 0 && H >= 1 && W >= 1 && C % 8 == 0 && C > 0 && C <= 1024 && Cout >= 1 && Cout <= 4);
-    FNET_CHECK_ARG(op.i[4] % 8 == 0 && op.i[5] % 8 == 0 && op.i[5] + C <= op.i[4]);
+    // C need not be a multiple of 8: channels C .. roundup8(C)-1 of the activation are zero padding inside ldc
+    FNET_CHECK_ARG(B > 0 && H >= 1 && W >= 1 && C > 0 && C <= 1024 && Cout >= 1 && Cout <= 4);
+    FNET_CHECK_ARG(op.i[4] % 8 == 0 && op.i[5] % 8 == 0 && op.i[5] + (C + 7) / 8 * 8 <= op.i[4]);
     FNET_CHECK_ARG(op.p[0] && op.p[1] && op.p[2] && op.p[3] && op.p[4] && (op.i[7] == 0 || op.i[7] == 1));
     const int total = B * H * W;
     const size_t lds = (size_t)(Cout * C + Cout) * sizeof(float);
@@ -537,12 +543,15 @@ int fnet_op_head_fwd(const FnetOp& op, hipStream_t st) {
     return FNET_OK;
 }
 
-// HEAD_BWD  i: 0 B,1 H,2 W,3 C,4 ldc,5 coff,6 ldc_d,7 coff_d,8 Cout,9 outact
+// HEAD_BWD  i: 0 B,1 H,2 W,3 C,4 ldc,5 coff,6 ldc_d,7 coff_d,8 Cout,9 outact,10 Cz (channels of dact written, 0 = roundup8(C); >= C: zeros)
 //           p: 0 dpred,1 z,2 pred,3 act (P),4 Wh,5 dact out (P interior),6 dWh (+=),7 dbh (+=)
 int fnet_op_head_bwd(const FnetOp& op, hipStream_t st) {
     const int B = op.i[0], H = op.i[1], W = op.i[2], C = op.i[3], Cout = op.i[8];
-    FNET_CHECK_ARG(B > 0 && H >= 1 && W >= 1 && C % 8 == 0 && C > 0 && C <= 64 && Cout >= 1 && Cout <= 4);
+    FNET_CHECK_ARG(B > 0 && H >= 1 && W >= 1 && C > 0 && C <= 64 && Cout >= 1 && Cout <= 4);
     FNET_CHECK_ARG(op.i[4] % 8 == 0 && op.i[5] % 8 == 0 && op.i[6] % 8 == 0 && op.i[7] % 8 == 0);
+    const int Cz = op.i[10] ? op.i[10] : (C + 7) / 8 * 8;
+    FNET_CHECK_ARG(Cz % 8 == 0 && Cz >= C && Cz <= 64);
+    FNET_CHECK_ARG(op.i[5] + (C + 7) / 8 * 8 <= op.i[4] && op.i[7] + Cz <= op.i[6]);
     for (int k = 0; k < 8; ++k) FNET_CHECK_ARG(op.p[k] != 0);
     const int total = B * H * W;
     int blocks = (total + kThreads * 8 - 1) / (kThreads * 8);
@@ -552,10 +561,10 @@ int fnet_op_head_bwd(const FnetOp& op, hipStream_t st) {
     DISPATCH_T(op.dtype, hipLaunchKernelGGL((k_head_bwd<T, 4, MAXC>), dim3(blocks), dim3(kThreads), lds, st,              \
                                             (const float*)op.p[0], (const float*)op.p[1], (const float*)op.p[2],           \
                                             (const T*)op.p[3], (const float*)op.p[4], (T*)op.p[5], (float*)op.p[6],        \
-                                            (float*)op.p[7], B, H, W, C, op.i[4], op.i[5], op.i[6], op.i[7], Cout, op.i[9]))
-    if (C <= 8) { HEAD_BWD_LAUNCH(8); }
-    else if (C <= 16) { HEAD_BWD_LAUNCH(16); }
-    else if (C <= 32) { HEAD_BWD_LAUNCH(32); }
+                                            (float*)op.p[7], B, H, W, C, op.i[4], op.i[5], op.i[6], op.i[7], Cout, op.i[9], Cz))
+    if (Cz <= 8) { HEAD_BWD_LAUNCH(8); }
+    else if (Cz <= 16) { HEAD_BWD_LAUNCH(16); }
+    else if (Cz <= 32) { HEAD_BWD_LAUNCH(32); }
     else { HEAD_BWD_LAUNCH(64); }
 #undef HEAD_BWD_LAUNCH
     FNET_LAUNCH_CHECK();

@@ -6,33 +6,36 @@ namespace {
 
 constexpr int kThreads = 256;
 
-// Wf[t][co][ci] = W[co][ci][t]            (ci < Cin, else 0)        forward conv, K dim = Cin_pad
-// Wd[t][ci][co] = W[co][ci][8-t]          (ci < Cin, else 0)        dgrad as a conv: rows = Cout_d (padded Cin), K dim = Cout
+// Wf[t][co][ci] = W[co][ci][t]            (ci < Cin and co < Cout, else 0)   forward conv, rows = Cout_pad, K dim = Cin_pad
+// Wd[t][ci][co] = W[co][ci][8-t]          (same)                              dgrad as a conv: rows = Cout_d (padded Cin), K dim = Cout_pad
+// Channel counts that are not a multiple of 8 (UNet_small-medium's 20) run zero-padded: the padded rows / columns are zeros here, the
+// matching norm and bias parameters read as zeros from the flat buffer's alignment gaps, so padded channels carry exact zeros.
 template <typename T>
-__global__ __launch_bounds__(256) void k_prep_weights(const float* W, T* Wf, T* Wd, int Cout, int Cin, int Cin_pad, int Cout_d, int blocked) {
+__global__ __launch_bounds__(256) void k_prep_weights(const float* W, T* Wf, T* Wd, int Cout, int Cin, int Cin_pad, int Cout_d, int blocked,
+                                                      int Cout_pad, int Kd /* K dim of Wd: >= Cout_pad (the MFMA kernel walks K in 16s) */) {
     // logical layouts Wf[t][co][ci], Wd[t][ci][co] (flipped taps); "blocked" (MFMA convolution) stores the K axis in
     // 16-channel blocks outermost, [K/16][t][row][16], so that one LDS-DMA stage of the conv is a contiguous slab
     const int idx = blockIdx.x * kThreads + threadIdx.x;
-    const int nf = 9 * Cout * Cin_pad;
-    const int nd = Wd ? 9 * Cout_d * Cout : 0;
+    const int nf = 9 * Cout_pad * Cin_pad;
+    const int nd = Wd ? 9 * Cout_d * Kd : 0;
     if (idx < nf) {
-        const int ci = idx % Cin_pad, co = (idx / Cin_pad) % Cout, t = idx / (Cin_pad * Cout);
-        const size_t o = (blocked & 1) ? ((((size_t)(ci >> 4) * 9 + t) * Cout + co) * 16 + (ci & 15)) : (size_t)idx;
-        st1<T>(Wf + o, ci < Cin ? W[((size_t)co * Cin + ci) * 9 + t] : 0.f);
+        const int ci = idx % Cin_pad, co = (idx / Cin_pad) % Cout_pad, t = idx / (Cin_pad * Cout_pad);
+        const size_t o = (blocked & 1) ? ((((size_t)(ci >> 4) * 9 + t) * Cout_pad + co) * 16 + (ci & 15)) : (size_t)idx;
+        st1<T>(Wf + o, (ci < Cin && co < Cout) ? W[((size_t)co * Cin + ci) * 9 + t] : 0.f);
     } else if (idx < nf + nd) {
         const int j = idx - nf;
-        const int co = j % Cout, ci = (j / Cout) % Cout_d, t = j / (Cout * Cout_d);
+        const int co = j % Kd, ci = (j / Kd) % Cout_d, t = j / (Kd * Cout_d);
         const size_t o = (blocked & 2) ? ((((size_t)(co >> 4) * 9 + t) * Cout_d + ci) * 16 + (co & 15)) : (size_t)j;
-        st1<T>(Wd + o, ci < Cin ? W[((size_t)co * Cin + ci) * 9 + (8 - t)] : 0.f);
+        st1<T>(Wd + o, (ci < Cin && co < Cout) ? W[((size_t)co * Cin + ci) * 9 + (8 - t)] : 0.f);
     }
 }
 
-// dW[co][ci][t] (+)= dWk[t][co][ci]
-__global__ __launch_bounds__(256) void k_unprep_wgrad(const float* dWk, float* dW, int Cout, int Cin, int Cin_w, int accumulate) {
+// dW[co][ci][t] (+)= dWk[t][co][ci]   (dWk rows = Cout_pad, row pitch Cin_w; padded rows / columns are dropped)
+__global__ __launch_bounds__(256) void k_unprep_wgrad(const float* dWk, float* dW, int Cout, int Cin, int Cin_w, int accumulate, int Cout_pad) {
     const int idx = blockIdx.x * kThreads + threadIdx.x;
     if (idx >= Cout * Cin * 9) return;
     const int t = idx % 9, ci = (idx / 9) % Cin, co = idx / (9 * Cin);
-    const float v = dWk[((size_t)t * Cout + co) * Cin_w + ci];
+    const float v = dWk[((size_t)t * Cout_pad + co) * Cin_w + ci];
     dW[idx] = accumulate ? dW[idx] + v : v;
 }
 
@@ -71,25 +74,27 @@ __global__ __launch_bounds__(256) void k_adam(float* p, const float* g, float* m
 
 }  // namespace
 
-// PREP_WEIGHTS  i: 0 Cout,1 Cin,2 Cin_pad,3 Cout_d; p: 0 W fp32 OIHW,1 Wf [9][Cout][Cin_pad],2 Wd [9][Cout_d][Cout]|0
+// PREP_WEIGHTS  i: 0 Cout,1 Cin,2 Cin_pad (K dim of Wf),3 Cout_d,4 blocked bits,5 Cout_pad (rows of Wf; 0 = Cout),6 Kd (K dim of Wd; 0 = Cout_pad)
+//               p: 0 W fp32 OIHW,1 Wf [9][Cout_pad][Cin_pad],2 Wd [9][Cout_d][Kd]|0
 int fnet_op_prep_weights(const FnetOp& op, hipStream_t st) {
-    const int Cout = op.i[0], Cin = op.i[1], Cin_pad = op.i[2], Cout_d = op.i[3];
-    FNET_CHECK_ARG(Cout > 0 && Cin > 0 && Cin_pad >= Cin && op.p[0] && op.p[1] && (op.p[2] == 0 || Cout_d >= Cin));
-    FNET_CHECK_ARG(op.i[4] >= 0 && op.i[4] <= 3 && (!(op.i[4] & 1) || Cin_pad % 16 == 0) && (!(op.i[4] & 2) || Cout % 16 == 0));
-    const int total = 9 * Cout * Cin_pad + (op.p[2] ? 9 * Cout_d * Cout : 0);
+    const int Cout = op.i[0], Cin = op.i[1], Cin_pad = op.i[2], Cout_d = op.i[3], Cout_pad = op.i[5] ? op.i[5] : Cout;
+    FNET_CHECK_ARG(Cout > 0 && Cin > 0 && Cin_pad >= Cin && Cout_pad >= Cout && op.p[0] && op.p[1] && (op.p[2] == 0 || Cout_d >= Cin));
+    const int Kd = op.i[6] ? op.i[6] : Cout_pad;
+    FNET_CHECK_ARG(op.i[4] >= 0 && op.i[4] <= 3 && (!(op.i[4] & 1) || Cin_pad % 16 == 0) && (!(op.i[4] & 2) || Kd % 16 == 0) && Kd >= Cout_pad);
+    const int total = 9 * Cout_pad * Cin_pad + (op.p[2] ? 9 * Cout_d * Kd : 0);
     DISPATCH_T(op.dtype, hipLaunchKernelGGL(k_prep_weights<T>, dim3((total + kThreads - 1) / kThreads), dim3(kThreads), 0, st,
-                                            (const float*)op.p[0], (T*)op.p[1], (T*)op.p[2], Cout, Cin, Cin_pad, Cout_d, op.i[4]));
+                                            (const float*)op.p[0], (T*)op.p[1], (T*)op.p[2], Cout, Cin, Cin_pad, Cout_d, op.i[4], Cout_pad, Kd));
     FNET_LAUNCH_CHECK();
     return FNET_OK;
 }
 
-// UNPREP_WGRAD  i: 0 Cout,1 Cin,2 Cin_w,3 accumulate; p: 0 dWk fp32 [9][Cout][Cin_w],1 dW fp32 OIHW
+// UNPREP_WGRAD  i: 0 Cout,1 Cin,2 Cin_w,3 accumulate,4 Cout_pad (0 = Cout); p: 0 dWk fp32 [9][Cout_pad][Cin_w],1 dW fp32 OIHW
 int fnet_op_unprep_wgrad(const FnetOp& op, hipStream_t st) {
-    const int Cout = op.i[0], Cin = op.i[1], Cin_w = op.i[2];
-    FNET_CHECK_ARG(Cout > 0 && Cin > 0 && Cin_w >= Cin && op.p[0] && op.p[1]);
+    const int Cout = op.i[0], Cin = op.i[1], Cin_w = op.i[2], Cout_pad = op.i[4] ? op.i[4] : Cout;
+    FNET_CHECK_ARG(Cout > 0 && Cin > 0 && Cin_w >= Cin && Cout_pad >= Cout && op.p[0] && op.p[1]);
     const int total = 9 * Cout * Cin;
     hipLaunchKernelGGL(k_unprep_wgrad, dim3((total + kThreads - 1) / kThreads), dim3(kThreads), 0, st, (const float*)op.p[0],
-                       (float*)op.p[1], Cout, Cin, Cin_w, op.i[3]);
+                       (float*)op.p[1], Cout, Cin, Cin_w, op.i[3], Cout_pad);
     FNET_LAUNCH_CHECK();
     return FNET_OK;
 }

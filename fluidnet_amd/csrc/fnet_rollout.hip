@@ -22,7 +22,9 @@ struct PV {            // channel view of a P-tensor
     bf16_t* ptr() const { return buf; }
 };
 
-struct ConvEnt { int cout, cin, cin_pad; long long w_off; bf16_t* Wf; };
+struct ConvEnt { int cout, cin, cin_pad; long long w_off; bf16_t* Wf; int cout_pad = 0, kf = 0; };
+inline int cpad(int c) { return (c + 7) / 8 * 8; }      // plan.py:cpad -- channel counts run zero-padded to a multiple of 8
+inline int kpad(int c) { return (c + 15) / 16 * 16; }   // plan.py:kpad -- K extent of the MFMA kernel's weights
 
 struct Rollout {
     FnetUNetConfig cfg;
@@ -52,7 +54,7 @@ struct Rollout {
     }
     PV pbuf(int h, int w, int C) { return PV{(bf16_t*)alloc((size_t)B * (h + 2) * (w + 2) * C * sizeof(bf16_t)), h, w, C, 0, C}; }
     float* pp(const std::string& name) { return params + off.at(name); }
-    int impl_for(int cin, int cout) const { return (cin % 16 == 0 && cout % 8 == 0) ? FNET_CONV_MFMA : FNET_CONV_REF; }
+    int impl_for(int cin, int cout) const { return (cin % 8 == 0 && cout % 8 == 0) ? FNET_CONV_MFMA : FNET_CONV_REF; }
 };
 
 FnetOp mkop(int code) {
@@ -82,7 +84,7 @@ void add_block(Rollout& r, const std::string& pre, int cin, int cout) {
             add_param(r, n + ".running_mean", cout);
             add_param(r, n + ".running_var", cout);
         }
-        r.convs[c] = ConvEnt{cout, ci[k], ci[k], r.off[c + ".weight"], nullptr};
+        r.convs[c] = ConvEnt{cout, ci[k], cpad(ci[k]), r.off[c + ".weight"], nullptr};
     }
 }
 void build_params(Rollout& r) {
@@ -176,9 +178,12 @@ void build_frame(Rollout& r) {
     // weights: fp32 OIHW -> bf16 forward layout, once per weight upload
     for (auto& kv : r.convs) {
         ConvEnt& ce = kv.second;
-        ce.Wf = (bf16_t*)r.alloc((size_t)9 * ce.cout * ce.cin_pad * sizeof(bf16_t));
+        ce.cout_pad = cpad(ce.cout);
+        const bool mfma = r.impl_for(ce.cin_pad, ce.cout_pad) == FNET_CONV_MFMA;
+        ce.kf = mfma ? kpad(ce.cin_pad) : ce.cin_pad;
+        ce.Wf = (bf16_t*)r.alloc((size_t)9 * ce.cout_pad * ce.kf * sizeof(bf16_t));
         FnetOp o = mkop(FNET_OP_PREP_WEIGHTS);
-        const int v[5] = {ce.cout, ce.cin, ce.cin_pad, 0, r.impl_for(ce.cin_pad, ce.cout) == FNET_CONV_MFMA ? 1 : 0};
+        const int v[7] = {ce.cout, ce.cin, ce.kf, 0, mfma ? 1 : 0, ce.cout_pad, 0};
         memcpy(o.i, v, sizeof(v));
         o.p[0] = (uint64_t)(r.params + ce.w_off); o.p[1] = (uint64_t)ce.Wf;
         r.prep.push_back(o);
@@ -193,7 +198,7 @@ void build_frame(Rollout& r) {
         o.p[3] = (uint64_t)r.prev; o.p[4] = (uint64_t)r.emit; o.p[5] = (uint64_t)r.coll; o.p[6] = (uint64_t)in_p.buf;
         r.frame.push_back(o);
     }
-    const int base = c.base_channels;
+    const int base = cpad(c.base_channels);
     PV x = r.pbuf(H, W, base);
     e_conv(r, in_p, r.convs.at("stem"), r.pp("stem.bias"), x, 16, base);
     {
@@ -203,7 +208,7 @@ void build_frame(Rollout& r) {
         o.p[0] = (uint64_t)x.buf;
         r.frame.push_back(o);
     }
-    int h = H, w = W, ch = base;
+    int h = H, w = W, ch = c.base_channels;
     std::vector<PV> cats;
     std::vector<int> Cs;
     for (int L = 0; L < c.depth; ++L) {
@@ -256,13 +261,13 @@ void build_frame(Rollout& r) {
         r.frame.push_back(o);
         const std::string u = "ups." + std::to_string(i);
         PV catv = PV{cats[L].buf, h, w, 2 * C, 0, 2 * C};
-        x = conv_block(r, u + ".block", catv, C / 2, nullptr, false);
-        if (c.use_residual) x = conv_block(r, u + ".res.b", x, C / 2, nullptr, true);
+        x = conv_block(r, u + ".block", catv, cpad(C / 2), nullptr, false);
+        if (c.use_residual) x = conv_block(r, u + ".res.b", x, cpad(C / 2), nullptr, true);
         ch = C / 2;
     }
     {
         FnetOp o = mkop(FNET_OP_HEAD_FWD);
-        const int v[8] = {B, H, W, x.C, x.ldc, x.coff, c.out_channels, c.output_activation};
+        const int v[8] = {B, H, W, ch, x.ldc, x.coff, c.out_channels, c.output_activation};
         memcpy(o.i, v, sizeof(v));
         o.p[0] = (uint64_t)x.buf; o.p[1] = (uint64_t)r.pp("head.weight"); o.p[2] = (uint64_t)r.pp("head.bias");
         o.p[3] = (uint64_t)r.z; o.p[4] = (uint64_t)r.pred;
@@ -285,7 +290,7 @@ void build_frame(Rollout& r) {
 
 int cfg_ok(const FnetUNetConfig& c, int B, int H, int W) {
     if (c.in_channels != 6 || c.out_channels != 3) return 0;
-    if (c.base_channels < 8 || c.base_channels > 64 || c.base_channels % 8) return 0;
+    if (c.base_channels < 8 || c.base_channels > 64 || c.base_channels % 4) return 0;
     if (c.depth < 1 || c.depth > 6 || c.bottleneck_blocks < 0 || c.bottleneck_blocks > 8) return 0;
     if (c.act < 0 || c.act > 4 || c.padding_mode < 0 || c.padding_mode > 3 || c.upsample < 0 || c.upsample > 1) return 0;
     if (c.output_activation < 0 || c.output_activation > 1 || (c.use_residual != 0 && c.use_residual != 1)) return 0;

@@ -164,6 +164,32 @@ def unet_param_shapes(cfg) -> "OrderedDict[str, Tuple[int, ...]]":
     return out
 
 
+def cpad(c: int) -> int:
+    """Channel count a tensor of `c` channels is laid out with: the next multiple of 8 (UNet_small-medium's 20 -> 24).  Padded
+    channels hold exact zeros: their conv rows / columns are zero (PREP_WEIGHTS) and their norm / bias parameters are the zero
+    alignment gaps of param_layout."""
+    return (c + 7) // 8 * 8
+
+
+def kpad(c: int) -> int:
+    """K extent of an MFMA convolution's weights over `c` input channels: the kernel walks K in 16-channel stages and, when c is
+    only a multiple of 8, lets the last stage run into the next pixel against zero weights."""
+    return (c + 15) // 16 * 16
+
+
+def param_layout(cfg) -> "Tuple[OrderedDict[str, Tuple[int, ...]], OrderedDict[str, int], int]":
+    """(shapes, offsets in floats, total floats) of the flat fp32 parameter / gradient / Adam buffers: tensors in state-dict order,
+    each 32-B aligned, per-channel vectors given cpad(C) floats so that kernels may read a padded layer's gamma / beta / bias as zeros."""
+    shapes = unet_param_shapes(cfg)
+    offs: "OrderedDict[str, int]" = OrderedDict()
+    off = 0
+    for k, s in shapes.items():
+        offs[k] = off
+        n = cpad(s[0]) if len(s) == 1 else int(np.prod(s))
+        off = (off + n + 7) // 8 * 8
+    return shapes, offs, off
+
+
 def group_size(groups: int, ch: int) -> int:
     """Channels per group of nn.GroupNorm as the reference builds it (unet.py:24-28): the largest g <= groups dividing ch."""
     g = min(groups, ch)
@@ -183,7 +209,7 @@ def norm_state_layout(cfg) -> "Tuple[OrderedDict[str, int], int]":
                 base = k[: -len(".weight")]
                 for leaf in ("running_mean", "running_var"):
                     offs[f"{base}.{leaf}"] = off
-                    off = (off + s[0] + 7) // 8 * 8
+                    off = (off + cpad(s[0]) + 7) // 8 * 8
     return offs, off
 
 
@@ -196,7 +222,7 @@ def wgrad_slab_parts(cfg) -> int:
     worst = 0
     for k, s in unet_param_shapes(cfg).items():
         if len(s) == 4 and s[2] == 3:
-            co, ci = s[0], max(16, s[1])
+            co, ci = cpad(s[0]), max(16, cpad(s[1]))
             nco, nci = (2 if co > 32 else 1), (2 if ci > 32 else 1)
             cot, cit = -(-co // (32 * nco)), -(-ci // (32 * nci))
             splits = -(-512 // (cot * cit))
@@ -217,8 +243,8 @@ def check_supported(cfg, H: int, W: int) -> None:
         bad.append(f"in_channels={cfg.in_channels} (only 6)")
     if not (1 <= cfg.out_channels <= 4):
         bad.append(f"out_channels={cfg.out_channels}")
-    if cfg.base_channels % 8 != 0:
-        bad.append(f"base_channels={cfg.base_channels} (multiple of 8)")
+    if cfg.base_channels % 4 != 0:
+        bad.append(f"base_channels={cfg.base_channels} (multiple of 4: every concatenated tensor needs a multiple of 8 channels)")
     if cfg.base_channels > 64:
         bad.append(f"base_channels={cfg.base_channels} (head kernels cover <= 64)")
     if cfg.depth < 1:
@@ -249,13 +275,7 @@ class PlanBuilder:
         self.s_slab: Optional[Buf] = None
         self._affine_pending: list = []
         self.pool: Dict[Tuple, List[Buf]] = {}
-        self.shapes = unet_param_shapes(cfg)
-        self.offsets: "OrderedDict[str, int]" = OrderedDict()
-        off = 0
-        for k, s in self.shapes.items():
-            self.offsets[k] = off
-            off += int(np.prod(s))
-            off = (off + 7) // 8 * 8           # keep every tensor 32-B aligned inside the flat buffers
+        self.shapes, self.offsets, off = param_layout(cfg)
         self.n_params_padded = off
         self.params = self.new_buf("params_flat", (off,), "f32", external=True)
         self.grads = self.new_buf("grads_flat", (off,), "f32", external=True)
@@ -276,12 +296,15 @@ class PlanBuilder:
             if len(s) == 4 and s[2] == 3:
                 name = k[: -len(".weight")]
                 co, ci = s[0], s[1]
-                cip = 16 if name == "stem" else ci       # only the 6-channel stem input is padded (to one MFMA k-step)
+                cip = 16 if name == "stem" else cpad(ci)  # the 6-channel stem input is padded to one MFMA k-step
+                cop = cpad(co)
+                kf = kpad(cip) if self.impl_for(cip, cop) == rt.CONV_MFMA else cip
+                kd = kpad(cop) if self.impl_for(cop, cip) == rt.CONV_MFMA else cop
                 self.convs[name] = dict(
-                    Cout=co, Cin=ci, Cin_pad=cip, Cout_d=cip,
-                    Wf=self.new_buf(f"Wf/{name}", (9, co, cip), "T"),
-                    Wd=self.new_buf(f"Wd/{name}", (9, cip, co), "T"),
-                    dWk=self.new_buf(f"dWk/{name}", (9, co, cip), "f32"))
+                    Cout=co, Cin=ci, Cin_pad=cip, Cout_d=cip, Cout_pad=cop, Kf=kf, Kd=kd,
+                    Wf=self.new_buf(f"Wf/{name}", (9, cop, kf), "T"),
+                    Wd=self.new_buf(f"Wd/{name}", (9, cip, kd), "T"),
+                    dWk=self.new_buf(f"dWk/{name}", (9, cop, cip), "f32"))
 
     # -------------------------------------------------------------------------------------------- buffers
     def new_buf(self, name, shape, kind, external=False) -> Buf:
@@ -335,7 +358,8 @@ class PlanBuilder:
         if not k:
             return
         run = k in (1, 3)
-        self.op(ops, "NORM_COMBINE", [self.B, C, k, group_size(self.cfg.group_norm_groups, C) if k == 2 else 1, HW], f=[1e-5, 0.1],
+        creal = self.shapes[norm + ".weight"][0]          # groups are formed over the real channels; zero padding keeps its own statistics
+        self.op(ops, "NORM_COMBINE", [self.B, C, k, group_size(self.cfg.group_norm_groups, creal) if k == 2 else 1, HW, creal], f=[1e-5, 0.1],
                 p=[Ref(st), self.nref(norm + ".running_mean") if run else None, self.nref(norm + ".running_var") if run else None],
                 tag=norm)
 
@@ -348,9 +372,9 @@ class PlanBuilder:
     def impl_for(self, cin: int, cout: int) -> int:
         if self.conv_impl == "ref" or self.dtype != rt.BF16:
             return rt.CONV_REF
-        ok = cin % 16 == 0 and cout % 8 == 0
+        ok = cin % 8 == 0 and cout % 8 == 0
         if self.conv_impl == "mfma" and not ok:
-            raise NotImplementedError(f"MFMA conv needs Cin%16==0 and Cout%8==0 (got {cin}->{cout})")
+            raise NotImplementedError(f"MFMA conv needs channel counts that are multiples of 8 (got {cin}->{cout})")
         return rt.CONV_MFMA if ok else rt.CONV_REF
 
     # -------------------------------------------------------------------------------------------- op emitters
@@ -390,7 +414,7 @@ class PlanBuilder:
     def e_wgrad(self, ops, src: PV, dout: PV, conv: str):
         c = self.convs[conv]
         npix = self.B * (src.H + 2) * (src.W + 2)
-        assert src.C == c["Cin_pad"] and dout.C == c["Cout"], (conv, src.C, dout.C)
+        assert src.C == c["Cin_pad"] and dout.C == c["Cout_pad"], (conv, src.C, dout.C)
         self.op(ops, "WGRAD", [npix, src.W + 2, src.C, src.ldc, src.coff, dout.C, dout.ldc, dout.coff,
                                self.impl_for(src.C, dout.C), c["Cin_pad"], self.B, src.H, self.wgrad_slab.numel // WG_PART],
                 p=[src.ref, dout.ref, Ref(c["dWk"]), Ref(self.wgrad_slab)], tag=conv)
@@ -441,15 +465,15 @@ class PlanBuilder:
         site = app * 64
         t.in_p = self.pbuf(f"{tn}/in_p", H, W, 16)
         self.e_pack(ops, planes, t.in_p)
-        base = cfg.base_channels
+        base = cpad(cfg.base_channels)
         s_p = self.pbuf(f"{tn}/stem", H, W, base)
         t.stem = PlainConv("stem", PV(t.in_p, 16), PV(s_p, base), 1)
         self.e_conv(ops, t.stem.xin, self.convs["stem"]["Wf"], self.pref("stem.bias"), t.stem.out, 16, base, tag="stem")
         self.op(ops, "PAD_RING", [B, H, W, base, base, 0, self.pm], p=[Ref(s_p)])
         x = t.stem.out
-        h, w, ch = H, W, base
+        h, w, ch = H, W, cfg.base_channels
         for L in range(cfg.depth):
-            C = ch * 2
+            C = ch * 2                          # a multiple of 8 (base % 4 == 0): only base-channel tensors are ever padded
             cat = self.pbuf(f"{tn}/cat{L}", h, w, 2 * C)
             skip = PV(cat, C, C)
             d = dict(cat=cat, C=C)
@@ -491,10 +515,10 @@ class PlanBuilder:
             self.op(ops, "UPSAMPLE2X", [B, h // 2, w // 2, C, x.ldc, x.coff, 2 * C, 0, 1 if cfg.upsample == "bilinear" else 0, self.pm],
                     p=[x.ref, Ref(d["cat"])], tag=f"ups.{i}.up")
             u = dict(cat=d["cat"], C=C, xlow=x)
-            u["block"] = self._conv_block(ops, tn, f"ups.{i}.block", PV(d["cat"], 2 * C, 0), C // 2, None, False, site); site += 1
+            u["block"] = self._conv_block(ops, tn, f"ups.{i}.block", PV(d["cat"], 2 * C, 0), cpad(C // 2), None, False, site); site += 1
             x = u["block"][1].out
             if cfg.use_residual:
-                u["res"] = self._conv_block(ops, tn, f"ups.{i}.res.b", x, C // 2, None, True, site); site += 1
+                u["res"] = self._conv_block(ops, tn, f"ups.{i}.res.b", x, cpad(C // 2), None, True, site); site += 1
                 x = u["res"][1].out
             else:
                 u["res"] = None
@@ -504,7 +528,7 @@ class PlanBuilder:
         co = cfg.out_channels
         t.z = self.new_buf(f"{tn}/z", (B, co, H, W), "f32")
         t.pred = pred if pred is not None else self.new_buf(f"{tn}/pred", (B, co, H, W), "f32")
-        self.op(ops, "HEAD_FWD", [B, H, W, x.C, x.ldc, x.coff, co, rt.OUTACT[cfg.output_activation]],
+        self.op(ops, "HEAD_FWD", [B, H, W, ch, x.ldc, x.coff, co, rt.OUTACT[cfg.output_activation]],
                 p=[x.ref, self.pref("head.weight"), self.pref("head.bias"), Ref(t.z), Ref(t.pred)], tag="head")
         return t
 
@@ -539,7 +563,8 @@ class PlanBuilder:
         if self.norm_kind:
             # BatchNorm2d / GroupNorm: centre with the gamma-weighted mean of S over the normalisation group (S stays for dgamma/dbeta)
             Sa = self.s_alloc(B * C * 2)
-            self.op(ops, "NORM_COMBINE_BWD", [B, C, self.norm_kind, group_size(self.cfg.group_norm_groups, C) if self.norm_kind == 2 else 1],
+            creal = self.shapes[u.norm + ".weight"][0]
+            self.op(ops, "NORM_COMBINE_BWD", [B, C, self.norm_kind, group_size(self.cfg.group_norm_groups, creal) if self.norm_kind == 2 else 1, creal],
                     p=[S, self.pref(u.norm + ".weight"), Sa], tag=u.norm)
         self.op(ops, "INACT_BWD_APPLY", [B, H, W, C, gl, gc, C, 0, C, 0, self.act, u.drop_site, self.seed, gf, self.pm,
                                          1 if self.norm_kind else 0], f=[u.drop_p],
@@ -625,7 +650,8 @@ class PlanBuilder:
         s_begin = 0
         x = t.head_in
         G = self.tmp(H, W, x.C)
-        self.op(ops, "HEAD_BWD", [B, H, W, x.C, x.ldc, x.coff, x.C, 0, cfg.out_channels, rt.OUTACT[cfg.output_activation]],
+        self.op(ops, "HEAD_BWD", [B, H, W, self.shapes["head.weight"][1], x.ldc, x.coff, x.C, 0, cfg.out_channels,
+                                  rt.OUTACT[cfg.output_activation], x.C],
                 p=[Ref(dpred), Ref(t.z), Ref(t.pred), x.ref, self.pref("head.weight"), Ref(G), self.gref("head.weight"),
                    self.gref("head.bias")], tag="head")
         srcs = [GradSrc(PV(G, x.C), 0)]
@@ -678,9 +704,9 @@ class PlanBuilder:
     # -------------------------------------------------------------------------------------------- weights / optimiser
     def emit_prep_weights(self, ops) -> None:
         for name, c in self.convs.items():
-            blocked = (1 if self.impl_for(c["Cin_pad"], c["Cout"]) == rt.CONV_MFMA else 0) | \
-                      (2 if self.impl_for(c["Cout"], c["Cout_d"]) == rt.CONV_MFMA else 0)
-            self.op(ops, "PREP_WEIGHTS", [c["Cout"], c["Cin"], c["Cin_pad"], c["Cout_d"], blocked],
+            blocked = (1 if self.impl_for(c["Cin_pad"], c["Cout_pad"]) == rt.CONV_MFMA else 0) | \
+                      (2 if self.impl_for(c["Cout_pad"], c["Cout_d"]) == rt.CONV_MFMA else 0)
+            self.op(ops, "PREP_WEIGHTS", [c["Cout"], c["Cin"], c["Kf"], c["Cout_d"], blocked, c["Cout_pad"], c["Kd"]],
                     p=[self.pref(name + ".weight"), Ref(c["Wf"]), Ref(c["Wd"])], tag=name)
 
     def emit_zero(self, ops, buf: Buf) -> None:
@@ -695,7 +721,7 @@ class PlanBuilder:
 
     def emit_unprep(self, ops) -> None:
         for name, c in self.convs.items():
-            self.op(ops, "UNPREP_WGRAD", [c["Cout"], c["Cin"], c["Cin_pad"], 0], p=[Ref(c["dWk"]), self.gref(name + ".weight")], tag=name)
+            self.op(ops, "UNPREP_WGRAD", [c["Cout"], c["Cin"], c["Cin_pad"], 0, c["Cout_pad"]], p=[Ref(c["dWk"]), self.gref(name + ".weight")], tag=name)
 
     # -------------------------------------------------------------------------------------------- loss
     def loss_ops_args(self, lc, tgt: Tuple[Ref, int], in0: Tuple[Ref, int], emit: Tuple[Ref, int], coll: Tuple[Ref, int]):

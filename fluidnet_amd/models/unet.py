@@ -17,7 +17,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from ..engine.plan import check_supported, norm_state_layout, unet_param_shapes
+from ..engine.plan import check_supported, norm_state_layout, param_layout
 from ..engine.unet_engine import UNetEngine
 
 NormType = Literal["none", "batch", "instance", "group"]
@@ -178,16 +178,12 @@ class UNet(nn.Module):
 
     # ------------------------------------------------------------------ flat parameter storage
     def _layout(self):
-        shapes = unet_param_shapes(self.cfg)
+        shapes, offsets, total = param_layout(self.cfg)
         names = [n for n, _ in self.named_parameters()]
         if names != list(shapes.keys()):
             raise NotImplementedError("fluidnet_amd HIP engine: unsupported parameter set for this UNetConfig "
                                       f"(norm={self.cfg.norm}, upsample={self.cfg.upsample}, downsample={self.cfg.downsample})")
-        off, offsets = 0, {}
-        for k, s in shapes.items():
-            offsets[k] = off
-            off = (off + int(np.prod(s)) + 7) // 8 * 8
-        return shapes, offsets, off
+        return shapes, offsets, total
 
     def _flatten(self) -> None:
         """(Re)pack all parameters into one flat buffer on their current device; parameters become views of it."""

@@ -190,7 +190,7 @@ int fnet_timer_destroy(void* timer);
 typedef struct FnetUNetConfig {
     int32_t in_channels;        /* 6 */
     int32_t out_channels;       /* 3 */
-    int32_t base_channels;      /* multiple of 8, <= 64 */
+    int32_t base_channels;      /* multiple of 4, <= 64 (not a multiple of 8: those tensors run zero-padded) */
     int32_t depth;
     int32_t act;                /* FNET_ACT_* */
     int32_t padding_mode;       /* FNET_PAD_* */

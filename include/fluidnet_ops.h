@@ -17,7 +17,8 @@
  *   i: 0 Npix, 1 Wp, 2 Cin, 3 ldc_in, 4 coff_in, 5 Cout, 6 ldc_out, 7 coff_out, 8 impl (FNET_CONV_*),
  *      9 floats available at p[4], 10 H (needed only when p[4] != 0)
  *   p: 0 src P, 1 weights (same element type as src): impl REF [9][Cout][Cin]; impl MFMA K-blocked
- *      [Cin/16][9][Cout][16] as written by PREP_WEIGHTS, 2 bias fp32|0, 3 dst P (every pixel incl.
+ *      [ceil(Cin/16)][9][Cout][16] as written by PREP_WEIGHTS (MFMA: Cin % 8 == 0 suffices -- the last K stage may
+ *      overrun 8 channels into the next pixel against the zero-padded weights), 2 bias fp32|0, 3 dst P (every pixel incl.
  *      ring is written; the ring is then overwritten by APPLY / PAD_RING),
  *      4 |0 per-tile InstanceNorm partial sums float2[ceil(Npix/256)][4][Cout] (MFMA only; consumed
  *      by IN_STATS mode 1)
@@ -48,7 +49,8 @@
  * PAD_RING          <- F.pad(mode=...) in place
  *   i: 0 B, 1 H, 2 W, 3 C, 4 ldc, 5 coff, 6 pm; p: 0 buf P
  * HEAD_FWD          <- 1x1 head conv + output activation (ml/models/unet.py:279, 294-303)
- *   i: 0 B, 1 H, 2 W, 3 C, 4 ldc, 5 coff, 6 Cout (<= 4), 7 FNET_OUT_*
+ *   i: 0 B, 1 H, 2 W, 3 C (real channels; need not be a multiple of 8: the tail up to the next 8 is zero padding),
+ *      4 ldc, 5 coff, 6 Cout (<= 4), 7 FNET_OUT_*
  *   p: 0 src P, 1 Wh fp32 [Cout][C], 2 bh, 3 z fp32 [B,Cout,H,W] (pre-activation), 4 pred fp32 [B,Cout,H,W]
  * LOSS_REDUCE       <- PhysicsAwareLoss.forward sums (ml/training/physics_loss.py:210-278)
  *   i: 0 B, 1 H, 2 W, 3 target bstride, 4 in0 bstride, 5 emitter bstride, 6 collider bstride, 7 pm, 8 stencil,
@@ -62,7 +64,8 @@
  *   p: 0..4 as LOSS_REDUCE, 5 sums, 6 |0 global count, 7 |0 dnext [B,>=4,H,W] (gradient arriving from
  *      rollout step k+1's input, trainer.py:354-376), 8 |0 grad scale float*, 9 dpred out [B,3,H,W]
  * HEAD_BWD          <- adjoint of HEAD_FWD
- *   i: 0 B, 1 H, 2 W, 3 C, 4 ldc, 5 coff, 6 ldc_d, 7 coff_d, 8 Cout, 9 FNET_OUT_*
+ *   i: 0 B, 1 H, 2 W, 3 C, 4 ldc, 5 coff, 6 ldc_d, 7 coff_d, 8 Cout, 9 FNET_OUT_*, 10 Cz (channels of dact written,
+ *      0 = C rounded up to 8; channels C .. Cz-1 get zeros)
  *   p: 0 dpred, 1 z, 2 pred, 3 act P, 4 Wh, 5 dact out P (interior), 6 dWh (+=), 7 dbh (+=)
  * INACT_BWD_REDUCE  <- pass 1 of the norm/activation/dropout adjoint
  *   i: 0 B, 1 H, 2 W, 3 C, 4 ldc_g1, 5 coff_g1, 6 ldc_g2, 7 coff_g2, 8 ldc_raw, 9 coff_raw, 10 ldc_G, 11 coff_G,
@@ -80,9 +83,10 @@
  *                      (kind 1, training; also updates the running statistics: momentum f[1], unbiased variance) or over the
  *                      channels of a group (kind 2), in place, every (n,c) receiving its pool's values; kind 3 = eval-mode
  *                      BatchNorm2d: statistics = the running ones (no IN_STATS needed)
- *                   i: 0 B, 1 C, 2 kind, 3 channels per group (kind 2), 4 H*W; f: 0 eps, 1 momentum
+ *                   i: 0 B, 1 C, 2 kind, 3 channels per group (kind 2), 4 H*W, 5 real C (0 = C; groups cover the real
+ *                      channels of a zero-padded layer); f: 0 eps, 1 momentum
  *                   p: 0 stats float2[B][C], 1 running_mean|0, 2 running_var|0
- * NORM_COMBINE_BWD  i: 0 B, 1 C, 2 kind, 3 channels per group; p: 0 S float2[B][C], 1 gamma, 2 Sw float2[B][C] out: the
+ * NORM_COMBINE_BWD  i: 0 B, 1 C, 2 kind, 3 channels per group, 4 real C (0 = C); p: 0 S float2[B][C], 1 gamma, 2 Sw float2[B][C] out: the
  *                      gamma-weighted mean of S over the normalisation group (kind 3: zeros), read by INACT_BWD_APPLY with i[15] = 1
  * AFFINE_GRAD       i: 0 B, 1 C; p: 0 S float2[B][C], 1 dgamma (+=), 2 dbeta (+=)
  * AFFINE_GRAD_MULTI AFFINE_GRAD of up to 7 norm layers in one launch (the plan batches a backward pass's 26 layers into 4)
@@ -104,10 +108,13 @@
  * UNPACK_GRAD       i: 0 B, 1 H, 2 W, 3 ldc, 4 nch, 5 pm; p: 0 d_in_pad P, 1 dx fp32 [B,nch,H,W]
  * ZERO              i: 0 bytes & 0x7fffffff, 1 bytes >> 31; p: 0 ptr
  * PREP_WEIGHTS      <- per-step weight re-layout (no reference counterpart: OIHW fp32 is the checkpoint format)
- *   i: 0 Cout, 1 Cin, 2 Cin_pad, 3 Cout_d, 4 blocked flags (bit0: Wf K-blocked [Cin_pad/16][9][Cout][16];
- *      bit1: Wd likewise) -- set for the MFMA conv, clear for the REF conv
- *   p: 0 W fp32 OIHW, 1 Wf [9][Cout][Cin_pad], 2 |0 Wd [9][Cout_d][Cout] (taps flipped, in/out swapped: data gradient)
- * UNPREP_WGRAD      i: 0 Cout, 1 Cin, 2 Cin_w, 3 accumulate; p: 0 dWk fp32 [9][Cout][Cin_w], 1 dW fp32 OIHW
+ *   i: 0 Cout, 1 Cin, 2 Cin_pad (K extent of Wf), 3 Cout_d (rows of Wd), 4 blocked flags (bit0: Wf K-blocked
+ *      [Cin_pad/16][9][Cout_pad][16]; bit1: Wd likewise) -- set for the MFMA conv, clear for the REF conv,
+ *      5 Cout_pad (rows of Wf, 0 = Cout), 6 Kd (K extent of Wd, 0 = Cout_pad); everything beyond the real Cout x Cin is zero:
+ *      that is how channel counts that are not multiples of 8 / 16 run (zero-padded tensors, K overrun of the MFMA conv)
+ *   p: 0 W fp32 OIHW, 1 Wf [9][Cout_pad][Cin_pad], 2 |0 Wd [9][Cout_d][Kd] (taps flipped, in/out swapped: data gradient)
+ * UNPREP_WGRAD      i: 0 Cout, 1 Cin, 2 Cin_w, 3 accumulate, 4 Cout_pad (rows of dWk, 0 = Cout)
+ *                   p: 0 dWk fp32 [9][Cout_pad][Cin_w], 1 dW fp32 OIHW (padded rows / columns dropped)
  * GRAD_NORM         <- clip_grad_norm_'s norm (ml/training/trainer.py:192-193)
  *   i: 0 n & 0x7fffffff, 1 n >> 31; p: 0 grads fp32, 1 sum of squares double* (+=; zero first)
  * ADAM              <- clip_grad_norm_'s scaling + torch.optim.Adam.step (no amsgrad, no weight decay; trainer.py:164-195)

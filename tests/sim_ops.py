@@ -142,10 +142,13 @@ class Sim:
     def op_CONV3X3(self, r):
         npix, Wp, cin, ldc_in, coff_in, cout, ldc_out, coff_out, impl = r.i[:9]
         src = self.rd(r.p[0], cin, ldc_in, coff_in)
-        Wk = r.p[1].buf.tensor.float()                     # [9][cout][cin]
-        assert tuple(Wk.shape) == (9, cout, cin), (r.tag, Wk.shape, cout, cin)
-        if impl == rt.CONV_MFMA:                           # the MFMA kernel reads the K-blocked layout [cin/16][9][cout][16]
-            Wk = Wk.reshape(cin // 16, 9, cout, 16).permute(1, 2, 0, 3).reshape(9, cout, cin)
+        Wk = r.p[1].buf.tensor.float()                     # [9][cout][K], K = cin (K = cin rounded up to 16 for the MFMA kernel)
+        K = Wk.shape[2]
+        assert tuple(Wk.shape[:2]) == (9, cout) and cin <= K < cin + 16, (r.tag, Wk.shape, cout, cin)
+        if impl == rt.CONV_MFMA:                           # the MFMA kernel reads the K-blocked layout [K/16][9][cout][16]
+            Wk = Wk.reshape(K // 16, 9, cout, 16).permute(1, 2, 0, 3).reshape(9, cout, K)
+        assert float(Wk[:, :, cin:].abs().max()) == 0.0 if K > cin else True      # what the kernel's K overrun multiplies by
+        Wk = Wk[:, :, :cin]
         xs, n = self._flat_conv_inputs(src, Wp)
         assert n == npix
         out = torch.zeros(npix, cout)
@@ -239,6 +242,7 @@ class Sim:
 
     def op_NORM_COMBINE(self, r):
         B, C, kind, gs, HW = r.i[:5]
+        cr = r.i[5] if len(r.i) > 5 and r.i[5] else C                # groups cover the real channels only
         eps, mom = r.f[0], r.f[1]
         st = r.p[0].buf.tensor.view(-1)[r.p[0].off: r.p[0].off + B * C * 2].view(B, C, 2)
         if kind == 3:
@@ -258,22 +262,24 @@ class Sim:
                 rm[:C] = (1 - mom) * rm[:C] + mom * m
                 rv[:C] = (1 - mom) * rv[:C] + mom * var * (n / max(n - 1.0, 1.0))
         else:
-            m = mean.view(B, C // gs, gs).mean(2, keepdim=True)
-            q = e2.view(B, C // gs, gs).mean(2, keepdim=True)
+            m = mean[:, :cr].reshape(B, cr // gs, gs).mean(2, keepdim=True)
+            q = e2[:, :cr].reshape(B, cr // gs, gs).mean(2, keepdim=True)
             var = (q - m * m).clamp_min(0)
-            st[:, :, 0] = m.expand(B, C // gs, gs).reshape(B, C)
-            st[:, :, 1] = torch.rsqrt(var + eps).expand(B, C // gs, gs).reshape(B, C)
+            st[:, :cr, 0] = m.expand(B, cr // gs, gs).reshape(B, cr)
+            st[:, :cr, 1] = torch.rsqrt(var + eps).expand(B, cr // gs, gs).reshape(B, cr)
 
     def op_NORM_COMBINE_BWD(self, r):
         B, C, kind, gs = r.i[:4]
+        cr = r.i[4] if len(r.i) > 4 and r.i[4] else C
         S = self.flat(r.p[0])[: B * C * 2].view(B, C, 2)
         gamma = self.flat(r.p[1])[:C]
         out = self.flat(r.p[2])[: B * C * 2].view(B, C, 2)
         if kind == 1:
             out.copy_((gamma[:, None] * S.mean(0)).expand(B, C, 2))
         elif kind == 2:
-            w = (gamma[None, :, None] * S).view(B, C // gs, gs, 2).mean(2, keepdim=True)
-            out.copy_(w.expand(B, C // gs, gs, 2).reshape(B, C, 2))
+            w = (gamma[None, :cr, None] * S[:, :cr]).reshape(B, cr // gs, gs, 2).mean(2, keepdim=True)
+            out.zero_()
+            out[:, :cr] = w.expand(B, cr // gs, gs, 2).reshape(B, cr, 2)
         else:
             out.zero_()
 
@@ -404,22 +410,24 @@ class Sim:
     def op_PREP_WEIGHTS(self, r):
         cout, cin, cin_pad, cout_d = r.i[:4]
         blocked = r.i[4] if len(r.i) > 4 else 0
+        cop = r.i[5] if len(r.i) > 5 and r.i[5] else cout          # padded rows / columns are zeros
+        kd = r.i[6] if len(r.i) > 6 and r.i[6] else cop
         W = self.flat(r.p[0])[: cout * cin * 9].view(cout, cin, 9).float()
-        Wf = torch.zeros(9, cout, cin_pad)
-        Wf[:, :, :cin] = W.permute(2, 0, 1)
+        Wf = torch.zeros(9, cop, cin_pad)
+        Wf[:, :cout, :cin] = W.permute(2, 0, 1)
         if blocked & 1:
-            Wf = Wf.reshape(9, cout, cin_pad // 16, 16).permute(2, 0, 1, 3).reshape(9, cout, cin_pad)
+            Wf = Wf.reshape(9, cop, cin_pad // 16, 16).permute(2, 0, 1, 3).reshape(9, cop, cin_pad)
         r.p[1].buf.tensor.copy_(Wf.to(self.T))
         if r.p[2] is not None:
-            Wd = torch.zeros(9, cout_d, cout)
-            Wd[:, :cin, :] = W.flip(2).permute(2, 1, 0)
+            Wd = torch.zeros(9, cout_d, kd)
+            Wd[:, :cin, :cout] = W.flip(2).permute(2, 1, 0)
             if blocked & 2:
-                Wd = Wd.reshape(9, cout_d, cout // 16, 16).permute(2, 0, 1, 3).reshape(9, cout_d, cout)
+                Wd = Wd.reshape(9, cout_d, kd // 16, 16).permute(2, 0, 1, 3).reshape(9, cout_d, kd)
             r.p[2].buf.tensor.copy_(Wd.to(self.T))
 
     def op_UNPREP_WGRAD(self, r):
         cout, cin, cin_w, accumulate = r.i[:4]
-        dWk = r.p[0].buf.tensor[:, :, :cin]
+        dWk = r.p[0].buf.tensor[:, :cout, :cin]
         v = dWk.permute(1, 2, 0).reshape(-1)
         d = self.flat(r.p[1])[: cout * cin * 9]
         if accumulate:
@@ -470,7 +478,10 @@ class Sim:
             dz = dp * ((z >= lo) & (z <= 1.0)).float()
         x = self.rd(r.p[3], C, ldc, coff)[:, 1:-1, 1:-1]
         Wh = self.flat(r.p[4])[: cout * C].view(cout, C)
-        self.wr(r.p[5], C, ldd, cd, torch.einsum("bohw,oc->bhwc", dz, Wh), interior_only=True)
+        cz = r.i[10] if len(r.i) > 10 and r.i[10] else (C + 7) // 8 * 8     # channels written: zero-padded tail included
+        dact = torch.zeros(B, H, W, cz)
+        dact[..., :C] = torch.einsum("bohw,oc->bhwc", dz, Wh)
+        self.wr(r.p[5], cz, ldd, cd, dact, interior_only=True)
         self.flat(r.p[6])[: cout * C] += torch.einsum("bohw,bhwc->oc", dz, x).reshape(-1)
         self.flat(r.p[7])[:cout] += dz.sum((0, 2, 3))
 

@@ -151,6 +151,7 @@ ARCHS = {
     "medium": (dict(), 128),
     "large": (dict(base_channels=48, depth=4, downsample="avgpool"), 64),        # UNet_large.yaml
     "medium-maxpool": (dict(base_channels=16, downsample="maxpool"), 64),
+    "small-medium": (dict(base_channels=20, downsample="avgpool"), 64),          # UNet_small-medium.yaml
     "small": (dict(base_channels=16, depth=2, norm="batch", upsample="nearest", downsample="avgpool", padding_mode="zeros"), 128),  # UNet_small.yaml
 }
 
@@ -161,7 +162,7 @@ def test_medium_bf16_mfma_vs_oracle(arch):
     cfg = orc.medium_config(dropout=0.0, **over)
     params = orc.make_params(cfg, seed=7)
     x0, y, _ = orc.synth_batch(2, 1, R, seed=202)
-    m = _model(cfg, params, "bf16", "mfma")
+    m = _model(cfg, params, "bf16", "auto" if cfg.base_channels % 8 else "mfma")
     x = torch.from_numpy(x0).to(DEV).requires_grad_(True)
     tgt = torch.from_numpy(y[:, 0]).to(DEV)
     out = m(x)

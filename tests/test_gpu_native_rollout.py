@@ -28,6 +28,7 @@ def _weights(cfg, seed):
     ("small-batchnorm-avgpool", orc.medium_config(dropout=0.0, base_channels=16, depth=2, norm="batch", upsample="nearest",
                                                   downsample="avgpool", padding_mode="zeros"), 2, 64),
     ("large-avgpool", orc.medium_config(dropout=0.0, base_channels=48, depth=4, downsample="avgpool"), 1, 64),
+    ("small-medium-base20", orc.medium_config(dropout=0.0, base_channels=20, downsample="avgpool"), 2, 32),      # UNet_small-medium.yaml
     ("groupnorm-maxpool", tiny_cfg(norm="group", act="silu", downsample="maxpool", base_channels=16, group_norm_groups=4), 2, 32),
 ])
 def test_native_rollout_equals_python_plan(name, cfg, B, R):

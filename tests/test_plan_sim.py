@@ -119,6 +119,22 @@ def test_group_norm_default_config_blocks():
     run_case(tiny_cfg(norm="group", base_channels=24, depth=1, group_norm_groups=5), loss_c2(16), 2, 16, 1)
 
 
+def test_channel_counts_not_a_multiple_of_8():
+    """UNet_small-medium (base 20, UNet_small-medium.yaml): the 20-channel tensors run zero-padded to 32, everything the reference
+    sees (losses, predictions, every gradient, real-shaped parameters) is unchanged; and base 12 with GroupNorm / BatchNorm2d, whose
+    groups and running statistics are formed over the real channels"""
+    run_case(tiny_cfg(base_channels=20, downsample="avgpool", dropout=0.2), loss_c2(16), 2, 16, 2, dropout_seed=7)
+    run_case(tiny_cfg(base_channels=12, norm="group", group_norm_groups=3, depth=1), loss_c2(16), 2, 16, 1)
+    run_case(tiny_cfg(base_channels=12, norm="batch", depth=1, use_residual=False), loss_c2(16), 2, 16, 2)
+    plan, *_ = run_case(tiny_cfg(base_channels=20), loss_c2(16), 1, 16, 1)
+    # the zero padding stays zero: the gaps of the flat gradient buffer received nothing
+    pb = plan.pb
+    used = torch.zeros(pb.n_params_padded, dtype=torch.bool)
+    for k, s in pb.shapes.items():
+        used[pb.offsets[k]: pb.offsets[k] + int(np.prod(s))] = True
+    assert float(pb.grads.tensor[~used].abs().max()) == 0.0
+
+
 def test_dropout_hash_matches_injected_masks():
     run_case(tiny_cfg(dropout=0.3), loss_c2(16), 3, 16, 2, dropout_seed=1234)
 

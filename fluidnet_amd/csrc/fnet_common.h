@@ -265,6 +265,8 @@ FNET_DECL_OP(fnet_op_pool2x);
 FNET_DECL_OP(fnet_op_pool2x_bwd);
 FNET_DECL_OP(fnet_op_norm_combine);
 FNET_DECL_OP(fnet_op_norm_combine_bwd);
+FNET_DECL_OP(fnet_op_depth2space);
+FNET_DECL_OP(fnet_op_space2depth);
 FNET_DECL_OP(fnet_op_fold_sum);
 FNET_DECL_OP(fnet_op_bias_grad);
 FNET_DECL_OP(fnet_op_zero_insert);

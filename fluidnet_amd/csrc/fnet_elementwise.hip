@@ -682,7 +682,7 @@ __global__ __launch_bounds__(256) void k_affine_grad_multi(const float* Sbase, f
     if (g == 0 && c < C) {
         const float2 r1 = red[threadIdx.x + 64], r2 = red[threadIdx.x + 128], r3 = red[threadIdx.x + 192];
         grads[u.db_off[j] + c] += (a + r1.x) + (r2.x + r3.x);
-        grads[u.dg_off[j] + c] += (b + r1.y) + (r2.y + r3.y);
+        if (u.dg_off[j] >= 0) grads[u.dg_off[j] + c] += (b + r1.y) + (r2.y + r3.y);     // -1: no scale parameter (norm = "none")
     }
 }
 
@@ -881,6 +881,49 @@ __global__ __launch_bounds__(256) void k_pool2x_bwd(const T* g, const T* xin, T*
         }
     }
     o.store(dst + ((size_t)row * Wp + x) * ldc_d + coff_d + c0);
+}
+
+// ------------------------------------------------------------------ DEPTH2SPACE / SPACE2DEPTH (nn.ConvTranspose2d(k=2, s=2), unet.py:150)
+// The transposed convolution is computed as a centre-tap convolution into 4*C channels (phase q = 2a + b outermost, PREP_WEIGHTS kind 1);
+// DEPTH2SPACE writes out[2i+a][2j+b][c] = src[i][j][q*C + c] + bias[c] over the whole padded domain of dst (ring per pm).
+template <typename T>
+__global__ __launch_bounds__(256) void k_depth2space(const T* src, const float* bias, T* dst, int B, int h, int w, int C, int ldc_s, int coff_s,
+                                                     int ldc_d, int coff_d, int pm) {
+    const int H = 2 * h, W = 2 * w, Hp = H + 2, Wp = W + 2, groups = C >> 3;
+    const int row = blockIdx.x;
+    const int n = row / Hp, y = row % Hp;
+    const int item = blockIdx.y * kThreads + threadIdx.x;
+    if (item >= Wp * groups) return;
+    const int x = item / groups, cg = item - x * groups, c0 = cg * 8;
+    const int Y = pad_src(y - 1, H, pm), X = pad_src(x - 1, W, pm);
+    Vec8<T> o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o.v[k] = 0.f;
+    if (Y >= 0 && X >= 0) {
+        const int q = (Y & 1) * 2 + (X & 1);
+        o.load(src + (((size_t)n * (h + 2) + (Y >> 1) + 1) * (w + 2) + (X >> 1) + 1) * ldc_s + coff_s + q * C + c0);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o.v[k] += bias[c0 + k];
+    }
+    o.store(dst + ((size_t)row * Wp + x) * ldc_d + coff_d + c0);
+}
+// adjoint: dst[i][j][q*C + c] = fold(g)[2i+a][2j+b][c] on the interior of the (h, w) grid, 0 on its ring
+template <typename T>
+__global__ __launch_bounds__(256) void k_space2depth(const T* g, T* dst, int B, int h, int w, int C, int ldc_g, int coff_g, int ldc_d, int coff_d,
+                                                     int fold, int pm) {
+    const int hp = h + 2, wp = w + 2, groups = (4 * C) >> 3;
+    const int row = blockIdx.x;
+    const int n = row / hp, y = row % hp;
+    const int item = blockIdx.y * kThreads + threadIdx.x;
+    if (item >= wp * groups) return;
+    const int x = item / groups, cg = item - x * groups, k0 = cg * 8;
+    const int q = k0 / C, c0 = k0 - q * C;
+    Vec8<T> o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o.v[k] = 0.f;
+    if (y >= 1 && y <= h && x >= 1 && x <= w)
+        fold_read8<T>(g + coff_g + c0, n, 2 * (y - 1) + (q >> 1), 2 * (x - 1) + (q & 1), 2 * h, 2 * w, ldc_g, pm, fold, o.v);
+    o.store(dst + ((size_t)row * wp + x) * ldc_d + coff_d + k0);
 }
 
 // ------------------------------------------------------------------ SUBSAMPLE_BIAS (stride-2 conv = stride-1 conv sampled at even pixels)
@@ -1178,7 +1221,7 @@ int fnet_op_affine_grad_multi(const FnetOp& op, hipStream_t st) {
     for (int j = 0; j < 7; ++j) {
         const int k = j < n ? j : 0;
         u.s_off[j] = op.i[2 + 4 * k]; u.C[j] = op.i[3 + 4 * k]; u.dg_off[j] = op.i[4 + 4 * k]; u.db_off[j] = op.i[5 + 4 * k];
-        FNET_CHECK_ARG(u.s_off[j] >= 0 && u.s_off[j] % 2 == 0 && u.C[j] > 0 && u.dg_off[j] >= 0 && u.db_off[j] >= 0);
+        FNET_CHECK_ARG(u.s_off[j] >= 0 && u.s_off[j] % 2 == 0 && u.C[j] > 0 && u.dg_off[j] >= -1 && u.db_off[j] >= 0);
         if (u.C[j] > cmax) cmax = u.C[j];
     }
     hipLaunchKernelGGL(k_affine_grad_multi, dim3((cmax + 63) / 64, n), dim3(kThreads), 0, st, (const float*)op.p[0], (float*)op.p[1], u, B);
@@ -1264,6 +1307,32 @@ int fnet_op_pool2x_bwd(const FnetOp& op, hipStream_t st) {
     DISPATCH_T(op.dtype, hipLaunchKernelGGL(k_pool2x_bwd<T>, row_grid(B * (2 * h + 2), (2 * w + 2) * (C / 8)), dim3(kThreads), 0, st,
                                             (const T*)op.p[0], (const T*)op.p[1], (T*)op.p[2], B, h, w, C, op.i[4], op.i[5], op.i[6],
                                             op.i[7], op.i[8], op.i[9], op.i[10], op.i[11], op.i[12]));
+    FNET_LAUNCH_CHECK();
+    return FNET_OK;
+}
+
+// DEPTH2SPACE  i: 0 B,1 h,2 w,3 C,4 ldc_s,5 coff_s,6 ldc_d,7 coff_d,8 pm; p: 0 src (h,w; 4C channels),1 bias fp32 [C],2 dst (2h,2w; C channels)
+int fnet_op_depth2space(const FnetOp& op, hipStream_t st) {
+    const int B = op.i[0], h = op.i[1], w = op.i[2], C = op.i[3];
+    FNET_CHECK_ARG(B > 0 && h >= 1 && w >= 1 && op.p[1]);
+    FNET_CHECK_ARG(vec_ok((void*)op.p[0], op.i[4], op.i[5], 4 * C, op.dtype));
+    FNET_CHECK_ARG(vec_ok((void*)op.p[2], op.i[6], op.i[7], C, op.dtype));
+    DISPATCH_T(op.dtype, hipLaunchKernelGGL(k_depth2space<T>, row_grid(B * (2 * h + 2), (2 * w + 2) * (C / 8)), dim3(kThreads), 0, st,
+                                            (const T*)op.p[0], (const float*)op.p[1], (T*)op.p[2], B, h, w, C, op.i[4], op.i[5], op.i[6],
+                                            op.i[7], op.i[8]));
+    FNET_LAUNCH_CHECK();
+    return FNET_OK;
+}
+
+// SPACE2DEPTH  i: 0 B,1 h,2 w,3 C,4 ldc_g,5 coff_g,6 ldc_d,7 coff_d,8 fold,9 pm; p: 0 g (2h,2w; C channels),1 dst (h,w; 4C channels, ring 0)
+int fnet_op_space2depth(const FnetOp& op, hipStream_t st) {
+    const int B = op.i[0], h = op.i[1], w = op.i[2], C = op.i[3];
+    FNET_CHECK_ARG(B > 0 && h >= 1 && w >= 1 && (op.i[8] == 0 || op.i[8] == 1));
+    FNET_CHECK_ARG(vec_ok((void*)op.p[0], op.i[4], op.i[5], C, op.dtype));
+    FNET_CHECK_ARG(vec_ok((void*)op.p[1], op.i[6], op.i[7], 4 * C, op.dtype));
+    DISPATCH_T(op.dtype, hipLaunchKernelGGL(k_space2depth<T>, row_grid(B * (h + 2), (w + 2) * (4 * C / 8)), dim3(kThreads), 0, st,
+                                            (const T*)op.p[0], (T*)op.p[1], B, h, w, C, op.i[4], op.i[5], op.i[6], op.i[7], op.i[8],
+                                            op.i[9]));
     FNET_LAUNCH_CHECK();
     return FNET_OK;
 }

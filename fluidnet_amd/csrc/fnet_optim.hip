@@ -30,6 +30,37 @@ __global__ __launch_bounds__(256) void k_prep_weights(const float* W, T* Wf, T* 
     }
 }
 
+// nn.ConvTranspose2d(C, C, kernel_size=2, stride=2) (unet.py:150; weight [ci][co][a][b]) as a convolution with 4*Cout output channels
+// (phase q = 2a + b outermost) whose only non-zero tap is the centre one; DEPTH2SPACE then interleaves the phases:
+// Wf[4][q*Cout + co][ci] = W[ci][co][a][b], Wd[4][ci][q*Cout + co] = the same (the centre tap is its own flip).
+template <typename T>
+__global__ __launch_bounds__(256) void k_prep_weights_t2(const float* W, T* Wf, T* Wd, int Cout, int Cin, int Kf, int Cout_d, int blocked, int Kd) {
+    const int idx = blockIdx.x * kThreads + threadIdx.x;
+    const int R = 4 * Cout;
+    const int nf = 9 * R * Kf;
+    const int nd = Wd ? 9 * Cout_d * Kd : 0;
+    if (idx < nf) {
+        const int ci = idx % Kf, row = (idx / Kf) % R, t = idx / (Kf * R);
+        const int q = row / Cout, co = row - q * Cout;
+        const size_t o = (blocked & 1) ? ((((size_t)(ci >> 4) * 9 + t) * R + row) * 16 + (ci & 15)) : (size_t)idx;
+        st1<T>(Wf + o, (t == 4 && ci < Cin) ? W[((size_t)ci * Cout + co) * 4 + q] : 0.f);
+    } else if (idx < nf + nd) {
+        const int j = idx - nf;
+        const int k = j % Kd, ci = (j / Kd) % Cout_d, t = j / (Kd * Cout_d);
+        const int q = k / Cout, co = k - q * Cout;
+        const size_t o = (blocked & 2) ? ((((size_t)(k >> 4) * 9 + t) * Cout_d + ci) * 16 + (k & 15)) : (size_t)j;
+        st1<T>(Wd + o, (t == 4 && k < R && ci < Cin) ? W[((size_t)ci * Cout + co) * 4 + q] : 0.f);
+    }
+}
+// dW[ci][co][a][b] (+)= dWk[4][q*Cout + co][ci]
+__global__ __launch_bounds__(256) void k_unprep_wgrad_t2(const float* dWk, float* dW, int Cout, int Cin, int Cin_w, int accumulate) {
+    const int idx = blockIdx.x * kThreads + threadIdx.x;
+    if (idx >= Cin * Cout * 4) return;
+    const int q = idx & 3, co = (idx >> 2) % Cout, ci = idx / (4 * Cout);
+    const float v = dWk[((size_t)4 * (4 * Cout) + q * Cout + co) * Cin_w + ci];
+    dW[idx] = accumulate ? dW[idx] + v : v;
+}
+
 // dW[co][ci][t] (+)= dWk[t][co][ci]   (dWk rows = Cout_pad, row pitch Cin_w; padded rows / columns are dropped)
 __global__ __launch_bounds__(256) void k_unprep_wgrad(const float* dWk, float* dW, int Cout, int Cin, int Cin_w, int accumulate, int Cout_pad) {
     const int idx = blockIdx.x * kThreads + threadIdx.x;
@@ -74,10 +105,23 @@ __global__ __launch_bounds__(256) void k_adam(float* p, const float* g, float* m
 
 }  // namespace
 
-// PREP_WEIGHTS  i: 0 Cout,1 Cin,2 Cin_pad (K dim of Wf),3 Cout_d,4 blocked bits,5 Cout_pad (rows of Wf; 0 = Cout),6 Kd (K dim of Wd; 0 = Cout_pad)
+// PREP_WEIGHTS  i: 0 Cout,1 Cin,2 Cin_pad (K dim of Wf),3 Cout_d,4 blocked bits,5 Cout_pad (rows of Wf; 0 = Cout),6 Kd (K dim of Wd; 0 = Cout_pad),
+//                  7 kind (0 conv3x3, 1 transposed 2x2 stride 2: see k_prep_weights_t2)
 //               p: 0 W fp32 OIHW,1 Wf [9][Cout_pad][Cin_pad],2 Wd [9][Cout_d][Kd]|0
 int fnet_op_prep_weights(const FnetOp& op, hipStream_t st) {
     const int Cout = op.i[0], Cin = op.i[1], Cin_pad = op.i[2], Cout_d = op.i[3], Cout_pad = op.i[5] ? op.i[5] : Cout;
+    if (op.i[7] == 1) {
+        // transposed 2x2 stride-2 convolution (i[7] = 1): W fp32 [Cin][Cout][2][2] -> Wf [9][4*Cout][Cin_pad], Wd [9][Cout_d][Kd], Kd >= 4*Cout
+        const int Kd = op.i[6] ? op.i[6] : 4 * Cout;
+        FNET_CHECK_ARG(Cout > 0 && Cin > 0 && Cin_pad >= Cin && op.p[0] && op.p[1] && (op.p[2] == 0 || (Cout_d >= Cin && Kd >= 4 * Cout)));
+        FNET_CHECK_ARG(op.i[4] >= 0 && op.i[4] <= 3 && (!(op.i[4] & 1) || Cin_pad % 16 == 0) && (!(op.i[4] & 2) || Kd % 16 == 0));
+        const int total = 9 * 4 * Cout * Cin_pad + (op.p[2] ? 9 * Cout_d * Kd : 0);
+        DISPATCH_T(op.dtype, hipLaunchKernelGGL(k_prep_weights_t2<T>, dim3((total + kThreads - 1) / kThreads), dim3(kThreads), 0, st,
+                                                (const float*)op.p[0], (T*)op.p[1], (T*)op.p[2], Cout, Cin, Cin_pad, Cout_d, op.i[4], Kd));
+        FNET_LAUNCH_CHECK();
+        return FNET_OK;
+    }
+    FNET_CHECK_ARG(op.i[7] == 0);
     FNET_CHECK_ARG(Cout > 0 && Cin > 0 && Cin_pad >= Cin && Cout_pad >= Cout && op.p[0] && op.p[1] && (op.p[2] == 0 || Cout_d >= Cin));
     const int Kd = op.i[6] ? op.i[6] : Cout_pad;
     FNET_CHECK_ARG(op.i[4] >= 0 && op.i[4] <= 3 && (!(op.i[4] & 1) || Cin_pad % 16 == 0) && (!(op.i[4] & 2) || Kd % 16 == 0) && Kd >= Cout_pad);
@@ -88,10 +132,18 @@ int fnet_op_prep_weights(const FnetOp& op, hipStream_t st) {
     return FNET_OK;
 }
 
-// UNPREP_WGRAD  i: 0 Cout,1 Cin,2 Cin_w,3 accumulate,4 Cout_pad (0 = Cout); p: 0 dWk fp32 [9][Cout_pad][Cin_w],1 dW fp32 OIHW
+// UNPREP_WGRAD  i: 0 Cout,1 Cin,2 Cin_w,3 accumulate,4 Cout_pad (0 = Cout),5 kind (0 conv3x3, 1 transposed 2x2); p: 0 dWk fp32 [9][Cout_pad][Cin_w],1 dW fp32 OIHW
 int fnet_op_unprep_wgrad(const FnetOp& op, hipStream_t st) {
     const int Cout = op.i[0], Cin = op.i[1], Cin_w = op.i[2], Cout_pad = op.i[4] ? op.i[4] : Cout;
     FNET_CHECK_ARG(Cout > 0 && Cin > 0 && Cin_w >= Cin && Cout_pad >= Cout && op.p[0] && op.p[1]);
+    if (op.i[5] == 1) {                      // transposed 2x2: dWk fp32 [9][4*Cout][Cin_w] -> dW [Cin][Cout][2][2]
+        const int n = Cin * Cout * 4;
+        hipLaunchKernelGGL(k_unprep_wgrad_t2, dim3((n + kThreads - 1) / kThreads), dim3(kThreads), 0, st, (const float*)op.p[0],
+                           (float*)op.p[1], Cout, Cin, Cin_w, op.i[3]);
+        FNET_LAUNCH_CHECK();
+        return FNET_OK;
+    }
+    FNET_CHECK_ARG(op.i[5] == 0);
     const int total = 9 * Cout * Cin;
     hipLaunchKernelGGL(k_unprep_wgrad, dim3((total + kThreads - 1) / kThreads), dim3(kThreads), 0, st, (const float*)op.p[0],
                        (float*)op.p[1], Cout, Cin, Cin_w, op.i[3], Cout_pad);

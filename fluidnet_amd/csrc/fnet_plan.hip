@@ -29,6 +29,8 @@ static int dispatch_op(const FnetOp& op, hipStream_t st) {
         case FNET_OP_POOL2X_BWD: return fnet_op_pool2x_bwd(op, st);
         case FNET_OP_NORM_COMBINE: return fnet_op_norm_combine(op, st);
         case FNET_OP_NORM_COMBINE_BWD: return fnet_op_norm_combine_bwd(op, st);
+        case FNET_OP_DEPTH2SPACE: return fnet_op_depth2space(op, st);
+        case FNET_OP_SPACE2DEPTH: return fnet_op_space2depth(op, st);
         case FNET_OP_FOLD_SUM: return fnet_op_fold_sum(op, st);
         case FNET_OP_BIAS_GRAD: return fnet_op_bias_grad(op, st);
         case FNET_OP_ZERO_INSERT: return fnet_op_zero_insert(op, st);

@@ -221,8 +221,9 @@ def wgrad_slab_parts(cfg) -> int:
     geometry of fnet_wgrad_mfma: ~512 blocks per launch, 4 waves each."""
     worst = 0
     for k, s in unet_param_shapes(cfg).items():
-        if len(s) == 4 and s[2] == 3:
-            co, ci = cpad(s[0]), max(16, cpad(s[1]))
+        if len(s) == 4 and s[2] in (2, 3):
+            # 3x3: [co][ci]; transposed 2x2 ([ci][co][2][2]): a centre-tap convolution into 4*co channels
+            co, ci = (cpad(s[0]), max(16, cpad(s[1]))) if s[2] == 3 else (4 * s[1], max(16, s[0]))
             nco, nci = (2 if co > 32 else 1), (2 if ci > 32 else 1)
             cot, cit = -(-co // (32 * nco)), -(-ci // (32 * nci))
             splits = -(-512 // (cot * cit))
@@ -233,12 +234,12 @@ def wgrad_slab_parts(cfg) -> int:
 def check_supported(cfg, H: int, W: int) -> None:
     """The HIP engine covers the UNet_medium family; anything else fails loudly (no fallback)."""
     bad = []
-    if cfg.norm not in ("instance", "batch", "group"):
-        bad.append(f"norm={cfg.norm!r} (only 'instance'/'batch'/'group')")
+    if cfg.norm not in ("instance", "batch", "group", "none"):
+        bad.append(f"norm={cfg.norm!r}")
     if cfg.downsample not in ("stride", "avgpool", "maxpool"):
         bad.append(f"downsample={cfg.downsample!r}")
-    if cfg.upsample not in ("bilinear", "nearest"):
-        bad.append(f"upsample={cfg.upsample!r} (only 'bilinear'/'nearest')")
+    if cfg.upsample not in ("bilinear", "nearest", "transpose"):
+        bad.append(f"upsample={cfg.upsample!r}")
     if cfg.in_channels != 6:
         bad.append(f"in_channels={cfg.in_channels} (only 6)")
     if not (1 <= cfg.out_channels <= 4):
@@ -287,7 +288,15 @@ class PlanBuilder:
         # per-wave partial results of the weight-gradient kernel (36 KB each); see wgrad_slab_parts()
         self.wgrad_slab = self.new_buf("wgrad_slab", (wgrad_slab_parts(cfg) * WG_PART,), "f32")
         # BatchNorm2d / GroupNorm ride on the InstanceNorm kernels: NORM_COMBINE pools the per-(n,c) statistics
-        self.norm_kind = {"instance": 0, "batch": 1 if training else 3, "group": 2}[cfg.norm]
+        self.norm_kind = {"instance": 0, "batch": 1 if training else 3, "group": 2, "none": 0}[cfg.norm]
+        # norm == "none" (conv + bias -> activation, unet.py:55-69) runs through the same kernels as an identity normalisation:
+        # statistics (0, 1), gamma = 1, beta = the conv bias; its adjoint centres nothing (zero sums, the weighted-S form)
+        self.no_norm = cfg.norm == "none"
+        if self.no_norm:
+            cm = cpad(cfg.base_channels * 2 ** cfg.depth)
+            self.ones = self.new_buf("const/ones", (cm,), "f32")
+            self.ident_stats = self.new_buf("const/identity_stats", (B * cm, 2), "f32")
+            self.zero_sums = self.new_buf("const/zero_sums", (B * cm, 2), "f32")
         self.nstate_offsets, n_ns = norm_state_layout(cfg)
         # running statistics: the caller may bind its own tensor (UNet's buffers) before allocate(); else see init_norm_state()
         self.nstate = self.new_buf("norm_state", (max(n_ns, 8),), "f32")
@@ -305,6 +314,19 @@ class PlanBuilder:
                     Wf=self.new_buf(f"Wf/{name}", (9, cop, kf), "T"),
                     Wd=self.new_buf(f"Wd/{name}", (9, cip, kd), "T"),
                     dWk=self.new_buf(f"dWk/{name}", (9, cop, cip), "f32"))
+            elif len(s) == 4 and s[2] == 2:
+                # nn.ConvTranspose2d(C, C, 2, stride=2) [ci][co][2][2]: a centre-tap convolution C -> 4C (phase-major), then DEPTH2SPACE
+                name = k[: -len(".weight")]
+                ci, co = s[0], s[1]
+                assert ci % 8 == 0 and co % 8 == 0
+                rows = 4 * co
+                kf = kpad(ci) if self.impl_for(ci, rows) == rt.CONV_MFMA else ci
+                kd = kpad(rows) if self.impl_for(rows, ci) == rt.CONV_MFMA else rows
+                self.convs[name] = dict(
+                    Cout=co, Cin=ci, Cin_pad=ci, Cout_d=ci, Cout_pad=rows, Kf=kf, Kd=kd, tr=1,
+                    Wf=self.new_buf(f"Wf/{name}", (9, rows, kf), "T"),
+                    Wd=self.new_buf(f"Wd/{name}", (9, ci, kd), "T"),
+                    dWk=self.new_buf(f"dWk/{name}", (9, rows, ci), "f32"))
 
     # -------------------------------------------------------------------------------------------- buffers
     def new_buf(self, name, shape, kind, external=False) -> Buf:
@@ -363,6 +385,12 @@ class PlanBuilder:
                 p=[Ref(st), self.nref(norm + ".running_mean") if run else None, self.nref(norm + ".running_var") if run else None],
                 tag=norm)
 
+    def gamma_ref(self, u: "Unit") -> Ref:
+        return Ref(self.ones) if self.no_norm else self.pref(u.norm + ".weight")
+
+    def beta_ref(self, u: "Unit") -> Ref:
+        return self.pref(u.conv + ".bias") if self.no_norm else self.pref(u.norm + ".bias")
+
     def pref(self, name: str) -> Ref:
         return Ref(self.params, self.offsets[name])
 
@@ -392,6 +420,8 @@ class PlanBuilder:
         c = self.convs.get(name.split("/")[0])
         if c is None:                       # not a layer of the network (unit tests drive e_conv directly)
             return 0.0
+        if c.get("tr"):                     # transposed 2x2: every input pixel feeds 4 output pixels, one tap each
+            return 2.0 * self.B * H * W * 4 * c["Cin"] * c["Cout"]
         fl = 2.0 * self.B * H * W * 9 * c["Cin"] * c["Cout"]
         return fl / 4 if name.split("/")[0].endswith(".down") else fl
 
@@ -431,7 +461,7 @@ class PlanBuilder:
         self.op(ops, "APPLY", [self.B, raw.H, raw.W, raw.C, raw.ldc, raw.coff, res.ldc if res else 8, res.coff if res else 0,
                                u.out.ldc, u.out.coff, self.act, self.pm, u.drop_site, self.seed],
                 f=[u.drop_p],
-                p=[raw.ref, Ref(u.st), self.pref(u.norm + ".weight"), self.pref(u.norm + ".bias"), res.ref if res else None, u.out.ref],
+                p=[raw.ref, Ref(u.st), self.gamma_ref(u), self.beta_ref(u), res.ref if res else None, u.out.ref],
                 tag=u.conv)
 
     # -------------------------------------------------------------------------------------------- forward
@@ -440,13 +470,13 @@ class PlanBuilder:
         H, W = xin.H, xin.W
         c = self.convs[conv]
         raw = self.pbuf(f"{tape_name}/{conv}/raw", H, W, cout)
-        st = self.new_buf(f"{tape_name}/{conv}/stats", (self.B, cout, 2), "f32")
+        st = self.ident_stats if self.no_norm else self.new_buf(f"{tape_name}/{conv}/stats", (self.B, cout, 2), "f32")
         if out is None:
             out = PV(self.pbuf(f"{tape_name}/{conv}/act", H, W, cout), cout)
         u = Unit(conv, norm, xin, raw, st, out, res, drop_site, drop_p)
         fused = self.fused_stats_ok(H, W, c["Cin_pad"], cout)
         self.e_conv(ops, xin, c["Wf"], None, PV(raw, cout), c["Cin_pad"], cout, tag=conv, stats=fused)
-        if self.norm_kind != 3:                 # eval-mode BatchNorm2d normalises with the running statistics alone
+        if self.norm_kind != 3 and not self.no_norm:   # eval-mode BatchNorm2d normalises with the running statistics alone
             self.e_stats(ops, PV(raw, cout), st, from_conv=fused)
         self.e_norm_combine(ops, norm, st, cout, H * W)
         self.e_apply(ops, u)
@@ -512,8 +542,16 @@ class PlanBuilder:
             C = d["C"]
             assert ch == C
             h, w = h * 2, w * 2
-            self.op(ops, "UPSAMPLE2X", [B, h // 2, w // 2, C, x.ldc, x.coff, 2 * C, 0, 1 if cfg.upsample == "bilinear" else 0, self.pm],
-                    p=[x.ref, Ref(d["cat"])], tag=f"ups.{i}.up")
+            if cfg.upsample == "transpose":
+                name = f"ups.{i}.up"
+                t4 = self.tmp(h // 2, w // 2, 4 * C)
+                self.e_conv(ops, x, self.convs[name]["Wf"], None, PV(t4, 4 * C), C, 4 * C, tag=name)
+                self.op(ops, "DEPTH2SPACE", [B, h // 2, w // 2, C, 4 * C, 0, 2 * C, 0, self.pm],
+                        p=[Ref(t4), self.pref(name + ".bias"), Ref(d["cat"])], tag=name)
+                self.release(t4)
+            else:
+                self.op(ops, "UPSAMPLE2X", [B, h // 2, w // 2, C, x.ldc, x.coff, 2 * C, 0, 1 if cfg.upsample == "bilinear" else 0, self.pm],
+                        p=[x.ref, Ref(d["cat"])], tag=f"ups.{i}.up")
             u = dict(cat=d["cat"], C=C, xlow=x)
             u["block"] = self._conv_block(ops, tn, f"ups.{i}.block", PV(d["cat"], 2 * C, 0), cpad(C // 2), None, False, site); site += 1
             x = u["block"][1].out
@@ -552,14 +590,14 @@ class PlanBuilder:
                 [B, H, W, C, g1.pv.ldc, g1.pv.coff, g2.pv.ldc if g2 else 8, g2.pv.coff if g2 else 0, C, 0, C, 0,
                  g1.fold, g2.fold if g2 else 0, self.act, self.pm, u.drop_site, self.seed],
                 f=[u.drop_p],
-                p=[g1.pv.ref, g2.pv.ref if g2 else None, Ref(u.raw), Ref(u.st), self.pref(u.norm + ".weight"),
-                   self.pref(u.norm + ".bias"), Ref(G) if G is not None else None, S], tag=u.conv)
+                p=[g1.pv.ref, g2.pv.ref if g2 else None, Ref(u.raw), Ref(u.st), self.gamma_ref(u),
+                   self.beta_ref(u), Ref(G) if G is not None else None, S], tag=u.conv)
         draw = self.tmp(H, W, C)
         if G is not None:
             gp, gl, gc, gf = Ref(G), C, 0, 0
         else:
             gp, gl, gc, gf = g1.pv.ref, g1.pv.ldc, g1.pv.coff, g1.fold
-        Sa = S
+        Sa = Ref(self.zero_sums) if self.no_norm else S
         if self.norm_kind:
             # BatchNorm2d / GroupNorm: centre with the gamma-weighted mean of S over the normalisation group (S stays for dgamma/dbeta)
             Sa = self.s_alloc(B * C * 2)
@@ -567,14 +605,17 @@ class PlanBuilder:
             self.op(ops, "NORM_COMBINE_BWD", [B, C, self.norm_kind, group_size(self.cfg.group_norm_groups, creal) if self.norm_kind == 2 else 1, creal],
                     p=[S, self.pref(u.norm + ".weight"), Sa], tag=u.norm)
         self.op(ops, "INACT_BWD_APPLY", [B, H, W, C, gl, gc, C, 0, C, 0, self.act, u.drop_site, self.seed, gf, self.pm,
-                                         1 if self.norm_kind else 0], f=[u.drop_p],
-                p=[gp, Ref(u.raw), Ref(u.st), self.pref(u.norm + ".weight"), self.pref(u.norm + ".bias"), Sa, Ref(draw)],
+                                         1 if (self.norm_kind or self.no_norm) else 0], f=[u.drop_p],
+                p=[gp, Ref(u.raw), Ref(u.st), self.gamma_ref(u), self.beta_ref(u), Sa, Ref(draw)],
                 tag=u.conv)
         for s in srcs:                      # only now: in the single-source form pass 2 still reads srcs[0]
             self.release(s.pv.buf)
         # dgamma/dbeta: a separate tiny kernel (adding them from every block of the reduce kernel, hundreds of adders per
         # address, cost more), batched over the layers of the backward pass by emit_backward (flush_affine)
-        self._affine_pending.append((S, C, self.gref(u.norm + ".weight"), self.gref(u.norm + ".bias"), u.norm))
+        if self.no_norm:                   # only the bias has a gradient: sum of dz (dgamma slot -1 = skipped)
+            self._affine_pending.append((S, C, None, self.gref(u.conv + ".bias"), u.conv))
+        else:
+            self._affine_pending.append((S, C, self.gref(u.norm + ".weight"), self.gref(u.norm + ".bias"), u.norm))
         self.e_wgrad(ops, u.xin, PV(draw, C), u.conv)
         dx = None
         if need_dx:
@@ -637,8 +678,8 @@ class PlanBuilder:
             grp = pend[k:k + 7]
             iv = [self.B, len(grp)]
             for (S, C, gw, gb, _) in grp:
-                assert S.buf is self.s_slab and gw.buf is self.grads and gb.buf is self.grads
-                iv += [S.off, C, gw.off, gb.off]
+                assert S.buf is self.s_slab and (gw is None or gw.buf is self.grads) and gb.buf is self.grads
+                iv += [S.off, C, gw.off if gw is not None else -1, gb.off]
             self.op(ops, "AFFINE_GRAD_MULTI", iv, p=[Ref(self.s_slab), Ref(self.grads)], tag="+".join(g[4] for g in grp))
 
     def emit_backward(self, ops, t: Tape, dpred: Buf, dx_out: Optional[Buf] = None, dx_channels: int = 6) -> None:
@@ -667,10 +708,22 @@ class PlanBuilder:
             dcat[L] = gcat.pv.buf                       # [.., 2C]: [0:C] -> upsample adjoint now, [C:2C] -> skip, later
             self.retain(dcat[L])
             h, w = u["xlow"].H, u["xlow"].W
-            glow = self.tmp(h, w, C)
-            self.op(ops, "UPSAMPLE2X_BWD", [B, h, w, C, 2 * C, 0, C, 0, 1, 1 if cfg.upsample == "bilinear" else 0, self.pm],
-                    p=[Ref(dcat[L]), Ref(glow)], tag=f"ups.{i}.up")
-            self.release(dcat[L])
+            if cfg.upsample == "transpose":
+                name = f"ups.{i}.up"
+                d4 = self.tmp(h, w, 4 * C)
+                self.op(ops, "SPACE2DEPTH", [B, h, w, C, 2 * C, 0, 4 * C, 0, 1, self.pm], p=[Ref(dcat[L]), Ref(d4)], tag=name)
+                self.release(dcat[L])
+                for q in range(4):              # the bias reaches every output pixel: all four phases
+                    self.op(ops, "BIAS_GRAD", [B, h, w, C, 4 * C, q * C], p=[Ref(d4), self.gref(name + ".bias")], tag=name)
+                self.e_wgrad(ops, u["xlow"], PV(d4, 4 * C), name)
+                glow = self.tmp(h, w, C)
+                self.e_conv(ops, PV(d4, 4 * C), self.convs[name]["Wd"], None, PV(glow, C), 4 * C, C, tag=name + "/dgrad")
+                self.release(d4)
+            else:
+                glow = self.tmp(h, w, C)
+                self.op(ops, "UPSAMPLE2X_BWD", [B, h, w, C, 2 * C, 0, C, 0, 1, 1 if cfg.upsample == "bilinear" else 0, self.pm],
+                        p=[Ref(dcat[L]), Ref(glow)], tag=f"ups.{i}.up")
+                self.release(dcat[L])
             srcs = [GradSrc(PV(glow, C), 0)]
         for j in reversed(range(len(t.mids))):
             srcs = self._block_bwd(ops, t.mids[j], srcs, True)
@@ -706,7 +759,7 @@ class PlanBuilder:
         for name, c in self.convs.items():
             blocked = (1 if self.impl_for(c["Cin_pad"], c["Cout_pad"]) == rt.CONV_MFMA else 0) | \
                       (2 if self.impl_for(c["Cout_pad"], c["Cout_d"]) == rt.CONV_MFMA else 0)
-            self.op(ops, "PREP_WEIGHTS", [c["Cout"], c["Cin"], c["Kf"], c["Cout_d"], blocked, c["Cout_pad"], c["Kd"]],
+            self.op(ops, "PREP_WEIGHTS", [c["Cout"], c["Cin"], c["Kf"], c["Cout_d"], blocked, c["Cout_pad"], c["Kd"], c.get("tr", 0)],
                     p=[self.pref(name + ".weight"), Ref(c["Wf"]), Ref(c["Wd"])], tag=name)
 
     def emit_zero(self, ops, buf: Buf) -> None:
@@ -721,7 +774,8 @@ class PlanBuilder:
 
     def emit_unprep(self, ops) -> None:
         for name, c in self.convs.items():
-            self.op(ops, "UNPREP_WGRAD", [c["Cout"], c["Cin"], c["Cin_pad"], 0, c["Cout_pad"]], p=[Ref(c["dWk"]), self.gref(name + ".weight")], tag=name)
+            self.op(ops, "UNPREP_WGRAD", [c["Cout"], c["Cin"], c["Cin_pad"], 0, c["Cout_pad"], c.get("tr", 0)],
+                    p=[Ref(c["dWk"]), self.gref(name + ".weight")], tag=name)
 
     # -------------------------------------------------------------------------------------------- loss
     def loss_ops_args(self, lc, tgt: Tuple[Ref, int], in0: Tuple[Ref, int], emit: Tuple[Ref, int], coll: Tuple[Ref, int]):
@@ -768,6 +822,10 @@ def allocate(pb: PlanBuilder, device) -> int:
         total += b.tensor.numel() * b.tensor.element_size()
         if b is pb.nstate:
             pb.init_norm_state()
+        if pb.no_norm and b is pb.ones:
+            b.tensor.fill_(1.0)
+        if pb.no_norm and b is pb.ident_stats:
+            b.tensor[:, 1] = 1.0
     return total
 
 

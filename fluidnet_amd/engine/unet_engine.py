@@ -70,7 +70,7 @@ class UNetEngine:
                 pb.emit_zero(zero, c["dWk"])
             unprep: List[OpRec] = []
             for name, c in pb.convs.items():
-                pb.op(unprep, "UNPREP_WGRAD", [c["Cout"], c["Cin"], c["Cin_pad"], 1, c["Cout_pad"]], p=[Ref(c["dWk"]), pb.gref(name + ".weight")], tag=name)
+                pb.op(unprep, "UNPREP_WGRAD", [c["Cout"], c["Cin"], c["Cin_pad"], 1, c["Cout_pad"], c.get("tr", 0)], p=[Ref(c["dWk"]), pb.gref(name + ".weight")], tag=name)
             allocate(pb, self.device)
             self._prep, self._zero_dwk, self._unprep_acc = lower(pb, prep), lower(pb, zero), lower(pb, unprep)
         else:

@@ -115,6 +115,8 @@ enum FnetOpCode {
     FNET_OP_POOL2X_BWD = 33,
     FNET_OP_NORM_COMBINE = 34,    /* BatchNorm2d / GroupNorm statistics pooled from the per-(n,c) ones (unet.py:20-28) */
     FNET_OP_NORM_COMBINE_BWD = 35,
+    FNET_OP_DEPTH2SPACE = 36,     /* phase interleave + bias of the transposed-conv upsample (unet.py:150) */
+    FNET_OP_SPACE2DEPTH = 37,
     FNET_OP_COUNT_
 };
 

@@ -90,7 +90,8 @@
  *                      gamma-weighted mean of S over the normalisation group (kind 3: zeros), read by INACT_BWD_APPLY with i[15] = 1
  * AFFINE_GRAD       i: 0 B, 1 C; p: 0 S float2[B][C], 1 dgamma (+=), 2 dbeta (+=)
  * AFFINE_GRAD_MULTI AFFINE_GRAD of up to 7 norm layers in one launch (the plan batches a backward pass's 26 layers into 4)
- *   i: 0 B, 1 n_units (<= 7), then per unit u at 2+4u: S offset (floats from p[0]), C, dgamma offset, dbeta offset (floats from p[1])
+ *   i: 0 B, 1 n_units (<= 7), then per unit u at 2+4u: S offset (floats from p[0]), C, dgamma offset (-1: none), dbeta offset
+ *      (floats from p[1])
  *   p: 0 S slab base, 1 flat gradient buffer base (+=)
  * FOLD_SUM          i: 0 B, 1 H, 2 W, 3 C, 4 ldc_g1, 5 coff_g1, 6 ldc_g2, 7 coff_g2, 8 ldc_d, 9 coff_d, 10 fold1, 11 fold2, 12 pm
  *                   p: 0 g1, 1 g2|0, 2 dst (interior = folded sum, ring = 0)
@@ -103,6 +104,12 @@
  * POOL2X_BWD        i: 0 B, 1 h, 2 w, 3 C, 4 ldc_g, 5 coff_g, 6 ldc_x, 7 coff_x, 8 ldc_d, 9 coff_d, 10 fold, 11 mode, 12 pm
  *                   p: 0 g P (h,w), 1 x P (2h,2w) = POOL2X's input (max only: the gradient goes to the first maximum of the
  *                      window in row-major order, as torch's max_pool2d) | 0, 2 dst P (2h,2w; whole padded domain, ring 0)
+ * DEPTH2SPACE       <- second half of nn.ConvTranspose2d(C, C, 2, stride=2) (unet.py:150): the first half is a CONV3X3 into 4C
+ *                      channels with PREP_WEIGHTS kind 1 weights (phase q = 2a+b outermost, centre tap only)
+ *                   i: 0 B, 1 h, 2 w, 3 C, 4 ldc_s, 5 coff_s, 6 ldc_d, 7 coff_d, 8 pm
+ *                   p: 0 src P (h,w; 4C channels), 1 bias fp32 [C], 2 dst P (2h,2w; C channels; whole padded domain, ring per pm)
+ * SPACE2DEPTH       <- its adjoint; i: 0 B, 1 h, 2 w, 3 C, 4 ldc_g, 5 coff_g, 6 ldc_d, 7 coff_d, 8 fold, 9 pm
+ *                   p: 0 g P (2h,2w; C channels), 1 dst P (h,w; 4C channels; ring 0)
  * UPSAMPLE2X_BWD    i: 0 B, 1 h, 2 w, 3 C, 4 ldc_g, 5 coff_g, 6 ldc_d, 7 coff_d, 8 fold, 9 mode, 10 pm
  *                   p: 0 g P (2h,2w), 1 dst P (h,w interior)
  * UNPACK_GRAD       i: 0 B, 1 H, 2 W, 3 ldc, 4 nch, 5 pm; p: 0 d_in_pad P, 1 dx fp32 [B,nch,H,W]
@@ -111,9 +118,11 @@
  *   i: 0 Cout, 1 Cin, 2 Cin_pad (K extent of Wf), 3 Cout_d (rows of Wd), 4 blocked flags (bit0: Wf K-blocked
  *      [Cin_pad/16][9][Cout_pad][16]; bit1: Wd likewise) -- set for the MFMA conv, clear for the REF conv,
  *      5 Cout_pad (rows of Wf, 0 = Cout), 6 Kd (K extent of Wd, 0 = Cout_pad); everything beyond the real Cout x Cin is zero:
- *      that is how channel counts that are not multiples of 8 / 16 run (zero-padded tensors, K overrun of the MFMA conv)
+ *      that is how channel counts that are not multiples of 8 / 16 run (zero-padded tensors, K overrun of the MFMA conv),
+ *      7 kind: 0 conv3x3 (W [Cout][Cin][3][3]); 1 transposed 2x2 stride 2 (W [Cin][Cout][2][2] -> Wf [9][4*Cout][Cin_pad],
+ *      Wd [9][Cout_d][Kd >= 4*Cout], centre tap only)
  *   p: 0 W fp32 OIHW, 1 Wf [9][Cout_pad][Cin_pad], 2 |0 Wd [9][Cout_d][Kd] (taps flipped, in/out swapped: data gradient)
- * UNPREP_WGRAD      i: 0 Cout, 1 Cin, 2 Cin_w, 3 accumulate, 4 Cout_pad (rows of dWk, 0 = Cout)
+ * UNPREP_WGRAD      i: 0 Cout, 1 Cin, 2 Cin_w, 3 accumulate, 4 Cout_pad (rows of dWk, 0 = Cout), 5 kind (as PREP_WEIGHTS)
  *                   p: 0 dWk fp32 [9][Cout_pad][Cin_w], 1 dW fp32 OIHW (padded rows / columns dropped)
  * GRAD_NORM         <- clip_grad_norm_'s norm (ml/training/trainer.py:192-193)
  *   i: 0 n & 0x7fffffff, 1 n >> 31; p: 0 grads fp32, 1 sum of squares double* (+=; zero first)

@@ -188,7 +188,7 @@ class Sim:
     def op_APPLY(self, r):
         B, H, W, C, ldc_raw, coff_raw, ldc_res, coff_res, ldc_dst, coff_dst, act, pm, site, seed = r.i[:14]
         raw = self.rd(r.p[0], C, ldc_raw, coff_raw)[:, 1:-1, 1:-1]
-        stats = r.p[1].buf.tensor if r.p[1] is not None else None
+        stats = self.flat(r.p[1])[: raw.shape[0] * C * 2].view(raw.shape[0], C, 2) if r.p[1] is not None else None
         gamma = self.flat(r.p[2])[:C] if r.p[2] is not None else None
         beta = self.flat(r.p[3])[:C] if r.p[3] is not None else None
         u, _ = self._u(raw, stats, gamma, beta)
@@ -209,7 +209,7 @@ class Sim:
         else:                                                   # single source, no G: pass 2 recomputes the same rounded value
             g = self.round(g)
         raw = self.rd(r.p[2], C, lr_, cr)[:, 1:-1, 1:-1]
-        u, xh = self._u(raw, r.p[3].buf.tensor, self.flat(r.p[4])[:C], self.flat(r.p[5])[:C])
+        u, xh = self._u(raw, self.flat(r.p[3])[: B * C * 2].view(B, C, 2), self.flat(r.p[4])[:C], self.flat(r.p[5])[:C])
         dz = g * self._drop(B, C, site, seed, r.f[0]) * act_bwd(u, act)
         S = torch.stack([dz.sum((1, 2)), (dz * xh).sum((1, 2))], -1)
         self.flat(r.p[7])[: B * C * 2] += S.reshape(-1)
@@ -225,7 +225,7 @@ class Sim:
         else:
             g = self.rd(r.p[0], C, lG, cG)[:, 1:-1, 1:-1]
         raw = self.rd(r.p[1], C, lr_, cr)[:, 1:-1, 1:-1]
-        stats = r.p[2].buf.tensor
+        stats = self.flat(r.p[2])[: B * C * 2].view(B, C, 2)
         gamma = self.flat(r.p[3])[:C]
         u, xh = self._u(raw, stats, gamma, self.flat(r.p[4])[:C])
         dz = g * self._drop(B, C, site, seed, r.f[0]) * act_bwd(u, act)
@@ -296,7 +296,8 @@ class Sim:
             s_off, C, dg, db = r.i[2 + 4 * j: 6 + 4 * j]
             S = slab[s_off: s_off + B * C * 2].view(B, C, 2)
             grads[db: db + C] += S[:, :, 0].sum(0)
-            grads[dg: dg + C] += S[:, :, 1].sum(0)
+            if dg >= 0:
+                grads[dg: dg + C] += S[:, :, 1].sum(0)
 
     def op_FOLD_SUM(self, r):
         B, H, W, C, l1, c1, l2, c2, ld, cd, fold1, fold2, pm = r.i[:13]
@@ -410,6 +411,8 @@ class Sim:
     def op_PREP_WEIGHTS(self, r):
         cout, cin, cin_pad, cout_d = r.i[:4]
         blocked = r.i[4] if len(r.i) > 4 else 0
+        if len(r.i) > 7 and r.i[7] == 1:
+            return self._prep_transposed(r)
         cop = r.i[5] if len(r.i) > 5 and r.i[5] else cout          # padded rows / columns are zeros
         kd = r.i[6] if len(r.i) > 6 and r.i[6] else cop
         W = self.flat(r.p[0])[: cout * cin * 9].view(cout, cin, 9).float()
@@ -425,8 +428,48 @@ class Sim:
                 Wd = Wd.reshape(9, cout_d, kd // 16, 16).permute(2, 0, 1, 3).reshape(9, cout_d, kd)
             r.p[2].buf.tensor.copy_(Wd.to(self.T))
 
+    def _prep_transposed(self, r):
+        """ConvTranspose2d(k=2, s=2) weight [ci][co][a][b] as a centre-tap convolution into 4*cout channels, phase q = 2a+b outermost"""
+        cout, cin, kf, cout_d, blocked = r.i[:5]
+        kd = r.i[6] if r.i[6] else 4 * cout
+        W = self.flat(r.p[0])[: cin * cout * 4].view(cin, cout, 4).float()
+        rows = W.permute(2, 1, 0).reshape(4 * cout, cin)            # [(q, co)][ci]
+        Wf = torch.zeros(9, 4 * cout, kf)
+        Wf[4, :, :cin] = rows
+        if blocked & 1:
+            Wf = Wf.reshape(9, 4 * cout, kf // 16, 16).permute(2, 0, 1, 3).reshape(9, 4 * cout, kf)
+        r.p[1].buf.tensor.copy_(Wf.to(self.T))
+        if r.p[2] is not None:
+            Wd = torch.zeros(9, cout_d, kd)
+            Wd[4, :cin, :4 * cout] = rows.t()
+            if blocked & 2:
+                Wd = Wd.reshape(9, cout_d, kd // 16, 16).permute(2, 0, 1, 3).reshape(9, cout_d, kd)
+            r.p[2].buf.tensor.copy_(Wd.to(self.T))
+
+    def op_DEPTH2SPACE(self, r):
+        B, h, w, C, ls, cs, ld, cd, pm = r.i[:9]
+        x = self.rd(r.p[0], 4 * C, ls, cs)[:, 1:-1, 1:-1].reshape(B, h, w, 2, 2, C)
+        y = x.permute(0, 1, 3, 2, 4, 5).reshape(B, 2 * h, 2 * w, C) + self.flat(r.p[1])[:C]
+        self.wr(r.p[2], C, ld, cd, pad_from_interior(y, pm))
+
+    def op_SPACE2DEPTH(self, r):
+        B, h, w, C, lg, cg, ld, cd, do_fold, pm = r.i[:10]
+        g = fold(self.rd(r.p[0], C, lg, cg), pm, do_fold)          # [B, 2h, 2w, C]
+        d = g.reshape(B, h, 2, w, 2, C).permute(0, 1, 3, 2, 4, 5).reshape(B, h, w, 4 * C)
+        out = torch.zeros(B, h + 2, w + 2, 4 * C)
+        out[:, 1:-1, 1:-1] = d
+        self.wr(r.p[1], 4 * C, ld, cd, out)
+
     def op_UNPREP_WGRAD(self, r):
         cout, cin, cin_w, accumulate = r.i[:4]
+        if len(r.i) > 5 and r.i[5] == 1:                            # transposed 2x2: dW[ci][co][q] from the centre tap
+            v = r.p[0].buf.tensor[4, :, :cin].reshape(4, cout, cin).permute(2, 1, 0).reshape(-1)
+            d = self.flat(r.p[1])[: cin * cout * 4]
+            if accumulate:
+                d += v
+            else:
+                d.copy_(v)
+            return
         dWk = r.p[0].buf.tensor[:, :cout, :cin]
         v = dWk.permute(1, 2, 0).reshape(-1)
         d = self.flat(r.p[1])[: cout * cin * 9]

@@ -206,7 +206,7 @@ def test_eval_mode_and_no_grad_and_cpu_rejection():
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         m(torch.from_numpy(x0))
     with pytest.raises(NotImplementedError):
-        UNet(UNetConfig(in_channels=6, norm="none", base_channels=16)).to(DEV)(torch.from_numpy(x0).to(DEV))
+        UNet(UNetConfig(in_channels=7, base_channels=16))(torch.zeros(3, 7, 32, 32, device=DEV))
     with pytest.raises(ValueError, match="depth must be >= 1"):
         UNet(UNetConfig(depth=0))
 

@@ -41,6 +41,9 @@ CASES = [
     ("bf16-mfma-batchnorm-small", dict(norm="batch", downsample="avgpool", upsample="nearest", dropout=0.1), "zeros", "bf16", "mfma", 16),
     ("fp32-ref-groupnorm", dict(norm="group", act="silu", use_residual=False), "zeros", "fp32", "ref", 8),
     ("bf16-mfma-groupnorm", dict(norm="group", act="silu", group_norm_groups=4), "replicate", "bf16", "mfma", 16),
+    ("fp32-ref-transpose-up", dict(upsample="transpose"), "reflect", "fp32", "ref", 8),
+    ("bf16-mfma-transpose-up", dict(upsample="transpose", dropout=0.1), "replicate", "bf16", "mfma", 16),
+    ("bf16-mfma-nonorm", dict(norm="none", dropout=0.2), "replicate", "bf16", "mfma", 16),
     ("fp32-ref-base20-small-medium", dict(downsample="avgpool", dropout=0.1), "replicate", "fp32", "ref", 20),
     ("bf16-auto-base20-small-medium", dict(downsample="avgpool", depth=3), "replicate", "bf16", "auto", 20),
     ("bf16-auto-base12-groupnorm", dict(norm="group", group_norm_groups=3), "zeros", "bf16", "auto", 12),

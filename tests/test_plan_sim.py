@@ -119,6 +119,19 @@ def test_group_norm_default_config_blocks():
     run_case(tiny_cfg(norm="group", base_channels=24, depth=1, group_norm_groups=5), loss_c2(16), 2, 16, 1)
 
 
+def test_norm_none_conv_bias_blocks():
+    """norm="none": ConvBlock convs carry a bias and nothing is normalised (unet.py:55-69)"""
+    run_case(tiny_cfg(norm="none", dropout=0.25, act="leaky_relu"), loss_c2(16), 2, 16, 2, dropout_seed=3)
+    run_case(tiny_cfg(norm="none", use_residual=False, downsample="maxpool", upsample="nearest"), loss_c2(16), 2, 16, 1)
+
+
+def test_transposed_conv_upsample():
+    """upsample="transpose": nn.ConvTranspose2d(C, C, kernel_size=2, stride=2) with bias in every Up (unet.py:149-150)"""
+    run_case(tiny_cfg(upsample="transpose"), loss_c2(16), 2, 16, 2)
+    run_case(tiny_cfg(upsample="transpose", padding_mode="reflect", use_residual=False, depth=1, norm="group"),
+             loss_c2(16, padding_mode="reflect"), 2, 16, 1)
+
+
 def test_channel_counts_not_a_multiple_of_8():
     """UNet_small-medium (base 20, UNet_small-medium.yaml): the 20-channel tensors run zero-padded to 32, everything the reference
     sees (losses, predictions, every gradient, real-shaped parameters) is unchanged; and base 12 with GroupNorm / BatchNorm2d, whose

@@ -57,6 +57,29 @@ def test_g1_golden_fp32(golden_dir):
         assert relerr(p.grad, g[f"grad/{k}"]) < 2e-4, k
 
 
+# the alternate block types of the reference's UNet, one combination each (the G5 fixtures of tests/golden/make_golden.py: outputs of
+# the imported reference model in training mode)
+G5 = {
+    "batch_relu_nearest_avgpool": dict(norm="batch", act="relu", upsample="nearest", downsample="avgpool", padding_mode="zeros"),
+    "group_silu_transpose_maxpool": dict(norm="group", act="silu", upsample="transpose", downsample="maxpool", padding_mode="reflect", group_norm_groups=3),
+    "none_leaky_bilinear_stride_nores": dict(norm="none", act="leaky_relu", use_residual=False, padding_mode="circular"),
+    "instance_sigmoid_tanh_mid2": dict(output_activation="sigmoid_tanh", bottleneck_blocks=2, depth=1),
+    "instance_zeros_mid0": dict(padding_mode="zeros", bottleneck_blocks=0),
+}
+
+
+@pytest.mark.parametrize("name", list(G5))
+def test_g5_golden_variants_forward_fp32(golden_dir, name):
+    g = np.load(os.path.join(golden_dir, "g5_variants_fwd.npz"))
+    cfg = tiny_cfg(**G5[name])
+    m = _model(cfg, orc.make_params(cfg, seed=17), "fp32")
+    assert [k for k, _ in m.named_parameters()] == [str(s) for s in g[f"{name}/param_names"]]
+    x0, _, _ = orc.synth_batch(2, 1, 32, seed=505)
+    with torch.no_grad():
+        out = m(torch.from_numpy(x0).to(DEV))
+    assert np.abs(out.cpu().numpy() - g[f"{name}/out"]).max() < 1e-4
+
+
 def test_g2_golden_medium_fp32(golden_dir):
     g = np.load(os.path.join(golden_dir, "g2_medium_step.npz"))
     cfg = orc.medium_config(dropout=0.0)

@@ -47,8 +47,11 @@ def variant_training_config(variant_name: str, manager: VariantManager, *, check
 
 
 def train_single_variant(variant_name: str, manager: VariantManager, npz_dir: Path, *, device: str = "cuda", precision: Optional[str] = None,
-                         use_hbm_loader: bool = False, seed: Optional[int] = None, engine: str = "plan") -> Trainer:
-    """ml/scripts/train.py:38-262 without the MLflow / evaluation tail.  Returns the finished Trainer."""
+                         use_hbm_loader: bool = False, seed: Optional[int] = None, engine: str = "plan", evaluate: bool = False,
+                         stats_path: Optional[Path] = None) -> Trainer:
+    """ml/scripts/train.py:38-262 without the MLflow tail.  Returns the finished Trainer; with `evaluate`, the reference's post-training
+    evaluation (train.py:247-256: best checkpoint -> run_test_evaluation + run_rollout_evaluation on the test split) is run and left in
+    `trainer.evaluation`."""
     config = variant_training_config(variant_name, manager)
     config.device = device
     torch.manual_seed(config.split_seed if seed is None else seed)
@@ -78,6 +81,14 @@ def train_single_variant(variant_name: str, manager: VariantManager, npz_dir: Pa
     trainer = Trainer(model, train_loader, val_loader, config, device, engine=engine)
     trainer.train()
     print(f"Training complete: {config.variant.full_model_name}\nBest model: {trainer.config.checkpoint_dir / 'best_model.pth'}")
+    trainer.evaluation = None
+    if evaluate and (Path(npz_dir) / "test").exists():
+        from .test_evaluation import run_rollout_evaluation, run_test_evaluation
+        best = trainer.config.checkpoint_dir / "best_model.pth"
+        if best.exists():
+            model.load_state_dict(torch.load(best, map_location="cpu", weights_only=True)["model_state_dict"])
+        trainer.evaluation = {"test": run_test_evaluation(model, config, device, npz_dir=npz_dir, stats_path=stats_path),
+                              "rollout": run_rollout_evaluation(model, config, device, npz_dir=npz_dir, stats_path=stats_path)}
     return trainer
 
 
@@ -105,12 +116,15 @@ def main(argv=None) -> None:
     ap.add_argument("--config-root", type=Path, required=True, help="directory with base_config.yaml, model_architectures/, variants/")
     ap.add_argument("--npz-dir", type=Path, required=True, help="directory with train/ and val/ seq_*.npz")
     ap.add_argument("--checkpoints", type=Path, required=True)
+    ap.add_argument("--evaluate", action="store_true", help="run the test-split and 30-step rollout evaluations after each variant")
+    ap.add_argument("--stats-path", type=Path, default=None, help="_field_stats.yaml (needed by --evaluate when the config normalises)")
     ap.add_argument("--no-deps", action="store_true")
     ap.add_argument("--force-retrain", action="store_true")
     ap.add_argument("--hbm-loader", action="store_true", help="keep the training split in HBM and gather batches on device")
     a = ap.parse_args(argv)
     m = VariantManager(a.config_root, a.checkpoints)
-    train_curriculum(m, a.variants, a.npz_dir, no_deps=a.no_deps, force_retrain=a.force_retrain, use_hbm_loader=a.hbm_loader)
+    train_curriculum(m, a.variants, a.npz_dir, no_deps=a.no_deps, force_retrain=a.force_retrain, use_hbm_loader=a.hbm_loader,
+                     evaluate=a.evaluate, stats_path=a.stats_path)
 
 
 if __name__ == "__main__":

@@ -93,3 +93,14 @@ def test_errors(tmp_path):
              velz=np.zeros((2, 4, 4), np.float32))
     with pytest.raises(ValueError):
         FluidNPZSequenceDataset(tmp_path, "train")
+
+
+def test_rollout_evaluation_starting_frames_rule():
+    """ml/training/test_evaluation.py:173-189"""
+    from fluidnet_amd.training.test_evaluation import _get_starting_frames
+    assert _get_starting_frames(120) == [20, 60, 89]
+    assert _get_starting_frames(40) == [9]                      # 20 + 30 does not fit (twice: the middle is 20 too), 9 + 30 < 40 does
+    assert _get_starting_frames(16, steps=5, points=[3, "middle", -6]) == [3, 8, 10]
+    assert _get_starting_frames(16, steps=5, points=[0, 11]) == []       # t >= 1 and t + steps < T
+
+

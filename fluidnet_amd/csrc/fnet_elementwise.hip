@@ -45,6 +45,8 @@ __device__ __forceinline__ void block_sum8(float (&v)[8], float* lds /* >= 8*4 f
 struct PackArgs {
     const float* src[6];
     int bstride[6];
+    int nplanes;           // 6 separate planes, or (plane_stride > 0) nplanes <= 16 planes of one NCHW tensor at src[0]
+    int plane_stride;
 };
 template <typename T>
 __global__ __launch_bounds__(256) void k_pack_input(PackArgs a, T* dst, int B, int H, int W, int Cpad, int pm) {
@@ -57,7 +59,9 @@ __global__ __launch_bounds__(256) void k_pack_input(PackArgs a, T* dst, int B, i
     T* d = dst + ((size_t)row * Wp + x) * Cpad;
     for (int c = 0; c < Cpad; ++c) {
         float v = 0.f;
-        if (c < 6 && sy >= 0 && sx >= 0) v = a.src[c][(size_t)n * a.bstride[c] + (size_t)sy * W + sx];
+        if (c < a.nplanes && sy >= 0 && sx >= 0)
+            v = a.plane_stride ? a.src[0][(size_t)n * a.bstride[0] + (size_t)c * a.plane_stride + (size_t)sy * W + sx]
+                               : a.src[c][(size_t)n * a.bstride[c] + (size_t)sy * W + sx];
         st1<T>(d + c, v);
     }
 }
@@ -1047,16 +1051,27 @@ inline bool cg_ok(int C, int B) { return C >= 8 && (C >> 3) <= kThreads && B > 0
 
 }  // namespace
 
-// PACK_INPUT  i: 0 B,1 H,2 W,3 Cpad,4 pm,5..10 batch strides of the six planes (elements)
+// PACK_INPUT  i: 0 B,1 H,2 W,3 Cpad,4 pm,5..10 batch strides of the six planes (elements),15 n (0: six planes; n: p[0] is one NCHW tensor of n channels)
 //             p: 0..5 source planes fp32 (plane n at src + n*stride, H*W contiguous), 6 dst P[B,H+2,W+2,Cpad]
 int fnet_op_pack_input(const FnetOp& op, hipStream_t st) {
     const int B = op.i[0], H = op.i[1], W = op.i[2], Cpad = op.i[3], pm = op.i[4];
     FNET_CHECK_ARG(B > 0 && H >= 2 && W >= 2 && Cpad >= 6 && Cpad % 8 == 0 && pm >= 0 && pm <= 3 && op.p[6]);
-    PackArgs a;
-    for (int c = 0; c < 6; ++c) {
-        FNET_CHECK_ARG(op.p[c] != 0 && op.i[5 + c] >= H * W);
-        a.src[c] = (const float*)op.p[c];
-        a.bstride[c] = op.i[5 + c];
+    PackArgs a = {};
+    if (op.i[15]) {
+        // i[15] = n: the n <= Cpad channels of ONE contiguous NCHW tensor at p[0] (batch stride i[5] >= n*H*W): the nn.Module path,
+        // where in_channels need not be the rollout's six fields
+        FNET_CHECK_ARG(op.i[15] >= 1 && op.i[15] <= Cpad && op.p[0] != 0 && op.i[5] >= op.i[15] * H * W);
+        a.src[0] = (const float*)op.p[0];
+        a.bstride[0] = op.i[5];
+        a.nplanes = op.i[15];
+        a.plane_stride = H * W;
+    } else {
+        for (int c = 0; c < 6; ++c) {
+            FNET_CHECK_ARG(op.p[c] != 0 && op.i[5 + c] >= H * W);
+            a.src[c] = (const float*)op.p[c];
+            a.bstride[c] = op.i[5 + c];
+        }
+        a.nplanes = 6;
     }
     DISPATCH_T(op.dtype, hipLaunchKernelGGL(k_pack_input<T>, row_grid(B * (H + 2), W + 2), dim3(kThreads), 0, st, a,
                                             (T*)op.p[6], B, H, W, Cpad, pm));

@@ -240,8 +240,8 @@ def check_supported(cfg, H: int, W: int) -> None:
         bad.append(f"downsample={cfg.downsample!r}")
     if cfg.upsample not in ("bilinear", "nearest", "transpose"):
         bad.append(f"upsample={cfg.upsample!r}")
-    if cfg.in_channels != 6:
-        bad.append(f"in_channels={cfg.in_channels} (only 6)")
+    if not (1 <= cfg.in_channels <= 16):
+        bad.append(f"in_channels={cfg.in_channels} (1..16; the K-step training and rollout plans need the reference's 6 fields)")
     if not (1 <= cfg.out_channels <= 4):
         bad.append(f"out_channels={cfg.out_channels}")
     if cfg.base_channels % 4 != 0:
@@ -409,9 +409,18 @@ class PlanBuilder:
     def op(self, ops, code, i, f=(), p=(), tag="") -> None:
         ops.append(OpRec(OPC[code], [int(v) for v in i], [float(v) for v in f], list(p), self.dtype, tag))
 
-    def e_pack(self, ops, planes: Sequence[Tuple[Ref, int]], dst: Buf):
-        assert len(planes) == 6
-        self.op(ops, "PACK_INPUT", [self.B, dst.shape[1] - 2, dst.shape[2] - 2, dst.shape[3], self.pm] + [s for _, s in planes],
+    def e_pack(self, ops, planes, dst: Buf):
+        """planes: six (Ref, batch stride) field planes (the rollout's channels), or ("nchw", Ref, n): one contiguous [B,n,H,W] tensor
+        (the nn.Module path, any in_channels <= 16)"""
+        H, W = dst.shape[1] - 2, dst.shape[2] - 2
+        if planes and planes[0] == "nchw":
+            _, ref, n = planes
+            assert n == self.cfg.in_channels
+            self.op(ops, "PACK_INPUT", [self.B, H, W, dst.shape[3], self.pm, n * H * W] + [0] * 9 + [n], p=[ref] + [None] * 5 + [Ref(dst)], tag=dst.name)
+            return
+        if len(planes) != 6 or self.cfg.in_channels != 6:
+            raise NotImplementedError("the K-step training and rollout plans feed the six fields of the reference's input (in_channels = 6)")
+        self.op(ops, "PACK_INPUT", [self.B, H, W, dst.shape[3], self.pm] + [s for _, s in planes],
                 p=[r for r, _ in planes] + [Ref(dst)], tag=dst.name)
 
     def conv_flops(self, name: str, H: int, W: int) -> float:

@@ -53,15 +53,15 @@ class UNetEngine:
         s = _Slot(len(self.slots))
         B, H, W = self.B, self.H, self.W
         HW = H * W
-        s.x = pb.new_buf(f"slot{s.idx}/x", (B, 6, H, W), "f32")
+        cin = self.cfg.in_channels
+        s.x = pb.new_buf(f"slot{s.idx}/x", (B, cin, H, W), "f32")
         s.dpred = pb.new_buf(f"slot{s.idx}/dpred", (B, self.cfg.out_channels, H, W), "f32")
-        s.dx = pb.new_buf(f"slot{s.idx}/dx", (B, 6, H, W), "f32")
+        s.dx = pb.new_buf(f"slot{s.idx}/dx", (B, cin, H, W), "f32")
         fwd: List[OpRec] = []
-        planes = [(Ref(s.x, c * HW), 6 * HW) for c in range(6)]
-        tape = pb.emit_forward(fwd, s.idx, planes)
+        tape = pb.emit_forward(fwd, s.idx, ("nchw", Ref(s.x), cin))
         s.pred = tape.pred
         bwd: List[OpRec] = []
-        pb.emit_backward(bwd, tape, s.dpred, s.dx, 6)
+        pb.emit_backward(bwd, tape, s.dpred, s.dx, cin)
         if self._prep is None:
             prep: List[OpRec] = []
             pb.emit_prep_weights(prep)

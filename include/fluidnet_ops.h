@@ -10,8 +10,9 @@
  * Npix = B*(H+2)*(W+2), Wp = W+2.  Reference citations are relative to the reference root.
  *
  * PACK_INPUT        <- torch.cat of the six input planes (ml/training/trainer.py:356) + the conv's own padding
- *   i: 0 B, 1 H, 2 W, 3 Cpad, 4 pm, 5..10 batch strides of the six planes (floats)
- *   p: 0..5 planes fp32 (sample n at p + n*stride, H*W contiguous), 6 dst P[.,Cpad] (channels >= 6 zero)
+ *   i: 0 B, 1 H, 2 W, 3 Cpad, 4 pm, 5..10 batch strides of the six planes (floats), 15 n (0: the six planes; n >= 1: p[0] is
+ *      ONE contiguous [B,n,H,W] tensor with batch stride i[5] -- the nn.Module path, any in_channels <= Cpad)
+ *   p: 0..5 planes fp32 (sample n at p + n*stride, H*W contiguous), 6 dst P[.,Cpad] (channels beyond the input's are zero)
  * CONV3X3           <- nn.Conv2d(k=3, padding=1) forward, and its data gradient on flipped weights
  *                      (ml/models/unet.py:55, 59, 92, 218; autograd's conv backward-data)
  *   i: 0 Npix, 1 Wp, 2 Cin, 3 ldc_in, 4 coff_in, 5 Cout, 6 ldc_out, 7 coff_out, 8 impl (FNET_CONV_*),

@@ -129,8 +129,13 @@ class Sim:
     def op_PACK_INPUT(self, r):
         B, H, W, Cpad, pm = r.i[:5]
         st = r.i[5:11]
-        x = torch.stack([self.planes(r.p[c], B, st[c], H * W).view(B, H, W) for c in range(6)], -1).float()
-        x = torch.cat([x, torch.zeros(B, H, W, Cpad - 6)], -1)
+        n = r.i[15] if len(r.i) > 15 and r.i[15] else 0
+        if n:                                                   # one contiguous NCHW tensor of n channels
+            x = self.planes(r.p[0], B, st[0], n * H * W).view(B, n, H, W).permute(0, 2, 3, 1).float()
+        else:
+            n = 6
+            x = torch.stack([self.planes(r.p[c], B, st[c], H * W).view(B, H, W) for c in range(6)], -1).float()
+        x = torch.cat([x, torch.zeros(B, H, W, Cpad - n)], -1)
         r.p[6].buf.tensor.copy_(pad_from_interior(x, pm).to(self.T))
 
     def _flat_conv_inputs(self, src, Wp):

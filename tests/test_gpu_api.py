@@ -229,7 +229,7 @@ def test_eval_mode_and_no_grad_and_cpu_rejection():
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         m(torch.from_numpy(x0))
     with pytest.raises(NotImplementedError):
-        UNet(UNetConfig(in_channels=7, base_channels=16))(torch.zeros(3, 7, 32, 32, device=DEV))
+        UNet(UNetConfig(in_channels=17, base_channels=16)).to(DEV)(torch.zeros(3, 17, 32, 32, device=DEV))
     with pytest.raises(ValueError, match="depth must be >= 1"):
         UNet(UNetConfig(depth=0))
 
@@ -293,3 +293,27 @@ def test_batch_norm_module_train_eval_and_state_dict():
     m2.load_state_dict(sd)
     with torch.no_grad():
         assert torch.equal(m2(x), e)
+
+
+def test_default_constructor_config():
+    """`UNet()` with the reference's own defaults (unet.py:183-201: 7 input channels, GroupNorm, SiLU, nearest, zeros, no residual,
+    depth 2): forward, input gradient and parameter gradients against the oracle, fp32 path."""
+    m = UNet(precision="fp32")
+    cfg = orc.OracleUNetConfig(**m.cfg.__dict__)
+    assert cfg.in_channels == 7 and cfg.norm == "group"
+    params = orc.make_params(cfg, seed=31)
+    m.load_state_dict(params)
+    m.to(DEV).train()
+    rs = np.random.RandomState(2)
+    x0 = rs.rand(2, 7, 32, 32).astype(np.float32)
+    x = torch.from_numpy(x0).to(DEV).requires_grad_(True)
+    out = m(x)
+    w = torch.from_numpy(rs.randn(*out.shape).astype(np.float32))
+    (out * w.to(DEV)).sum().backward()
+    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    xo = torch.from_numpy(x0).requires_grad_(True)
+    oout = orc.unet_forward(p, cfg, xo, training=True)
+    (oout * w).sum().backward()
+    assert (out.detach().cpu() - oout.detach()).abs().max() < 1e-4
+    assert relerr(x.grad, xo.grad) < 2e-4
+    assert max(relerr(v.grad, p[k].grad) for k, v in m.named_parameters()) < 2e-4

@@ -288,6 +288,15 @@ def test_batch_norm_module_train_eval_and_state_dict():
         e = m(x)
     eref = orc.unet_forward(params, cfg, torch.from_numpy(x0), training=False, bn_state=bn)
     assert (e.cpu() - eref).abs().max() < 2e-4
+    # eval-mode backward: BatchNorm2d is an affine map of the running statistics (nothing is centred)
+    xg = torch.from_numpy(x0).to(DEV).requires_grad_(True)
+    m.zero_grad()
+    m(xg).square().sum().backward()
+    pe = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    xo = torch.from_numpy(x0).requires_grad_(True)
+    orc.unet_forward(pe, cfg, xo, training=False, bn_state=bn).square().sum().backward()
+    assert relerr(xg.grad, xo.grad) < 2e-4
+    assert max(relerr(v.grad, pe[k].grad) for k, v in m.named_parameters()) < 2e-4
     # a reference-format checkpoint round trip keeps the statistics (buffers stay views of the flat norm state)
     m2 = _model(cfg, orc.make_params(cfg, seed=5), "fp32", train=False)
     m2.load_state_dict(sd)

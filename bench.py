@@ -46,12 +46,14 @@ ARCHS = {
 PUBLISHED_B1_128_FPS = {"medium": 200.0, "small": 1000.0}
 
 
-def arch_cfg(arch, dropout=None):
+def arch_cfg(arch, dropout=None, depth=None):
     kw = dict(in_channels=6, out_channels=3, base_channels=32, depth=3, norm="instance", act="gelu", dropout=0.1, upsample="bilinear",
               downsample="stride", padding_mode="replicate", use_residual=True, bottleneck_blocks=1, output_activation="linear_clamp")
     kw.update(ARCHS[arch])
     if dropout is not None:
         kw["dropout"] = dropout
+    if depth is not None:
+        kw["depth"] = depth
     return UNetConfig(**kw)
 
 
@@ -90,9 +92,9 @@ def barrier(world):
 
 
 class TrainStepper:
-    def __init__(self, B, R, K, precision, world, rank, lr=3e-4, conv_impl="auto", arch="medium"):
+    def __init__(self, B, R, K, precision, world, rank, lr=3e-4, conv_impl="auto", arch="medium", depth=None):
         torch.manual_seed(42)
-        self.model = UNet(arch_cfg(arch), precision=precision, conv_impl=conv_impl).cuda()
+        self.model = UNet(arch_cfg(arch, depth=depth), precision=precision, conv_impl=conv_impl).cuda()
         self.world = world
         self.lr = lr
         self.plan = RolloutTrainPlan(self.model.cfg, c2_loss(R), B, R, R, K, dtype=precision, conv_impl=conv_impl, world=world,
@@ -240,6 +242,7 @@ def main():
     ap.add_argument("--res", type=int, default=None)
     ap.add_argument("--k", type=int, default=4)
     ap.add_argument("--arch", choices=list(ARCHS), default="medium", help="model architecture (default: the headline's UNet_medium)")
+    ap.add_argument("--depth", type=int, default=None, help="override the architecture's encoder depth (BASELINE config 4: deeper encoders at 256^2 / 512^2)")
     ap.add_argument("--precision", default="bf16")
     ap.add_argument("--conv-impl", default="auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -257,7 +260,7 @@ def main():
         R = a.res or 128
         steps = a.steps if a.steps is not None else 10
         warm = a.warmup if a.warmup is not None else 3
-        st = TrainStepper(a.batch, R, a.k, a.precision, world, rank, conv_impl=a.conv_impl, arch=a.arch)
+        st = TrainStepper(a.batch, R, a.k, a.precision, world, rank, conv_impl=a.conv_impl, arch=a.arch, depth=a.depth)
         for _ in range(warm):
             st.step()
         barrier(world)
@@ -278,7 +281,7 @@ def main():
                "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": steps, "warmup": warm,
                "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": a.precision, "data": "synthetic",
-               "config": {"workload": f"UNet_{a.arch} K{a.k} rollout training {R}x{R}, batch {a.batch}/GPU, MSE+divergence+gradient+emitter, "
+               "config": {"workload": f"UNet_{a.arch}{'' if a.depth is None else f' depth {a.depth}'} K{a.k} rollout training {R}x{R}, batch {a.batch}/GPU, MSE+divergence+gradient+emitter, "
                                       f"BPTT through all K, clip 1.0 + Adam, dropout {st.model.cfg.dropout}", "global_batch": a.batch * world,
                           "parallelism": f"dp{world}", "final_loss": round(loss["total"], 6),
                           "hbm_bytes_allocated": st.bytes}}
@@ -310,7 +313,7 @@ def main():
         frames = a.steps if a.steps is not None else 600
         warm = a.warmup if a.warmup is not None else 10
         torch.manual_seed(42)
-        model = UNet(arch_cfg(a.arch, dropout=0.0), precision=a.precision, conv_impl=a.conv_impl).cuda().eval()
+        model = UNet(arch_cfg(a.arch, dropout=0.0, depth=a.depth), precision=a.precision, conv_impl=a.conv_impl).cuda().eval()
         plan = RolloutInferPlan(model.cfg, a.batch, R, R, params_flat=model.flat_params, dtype=a.precision, conv_impl=a.conv_impl,
                                 norm_state=model.flat_norm_state)
         em, co = simple_infer_masks(R, scale=R / 128.0)

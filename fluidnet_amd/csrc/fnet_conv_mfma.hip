@@ -29,7 +29,6 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 constexpr int kThreads = 256;
 constexpr int TM = 256;     // pixels per block
 constexpr int KC = 16;      // channels per LDS stage (= K of one MFMA)
-constexpr int PS = 48;      // (weight-gradient kernel) LDS pitch of a 16-channel row, bytes
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void gbl_void_t;
@@ -549,7 +548,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_dma(const bf16_t* __restrict__
     const int cop = wave % NCO, cip = (wave / NCO) % NCI, ksl = wave / (NCO * NCI);
     const int co_tile = blockIdx.y, ci_tile = blockIdx.z;
     const int co_base = co_tile * (32 * NCO), ci_base = ci_tile * (32 * NCI);
-    const int Hp = H + 2, Wp = W + 2;
+    const int Wp = W + 2;
     const int CW = 1 << log2cw, CH = WG_PX >> log2cw, SW = CW + 2;
     const int ncx = (W + CW - 1) >> log2cw, ncy = (H + CH - 1) / CH;
     const int cpi = ncx * ncy;                       // chunks per image

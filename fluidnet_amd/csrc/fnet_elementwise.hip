@@ -422,7 +422,8 @@ template <typename T>
 __device__ __forceinline__ void fold_read8(const T* g, int n, int y, int x, int H, int W, int ldc, int pm, int fold,
                                            float (&acc)[8]) {
     const int Hp = H + 2, Wp = W + 2;
-    if (!fold) {
+    // ring copies fold only onto the two outermost rows / columns (pad_lo / pad_hi of every padding mode): elsewhere a plain read
+    if (!fold || (y >= 2 && y <= H - 3 && x >= 2 && x <= W - 3)) {
         Vec8<T> v;
         v.load(g + (((size_t)n * Hp + y + 1) * Wp + x + 1) * ldc);
 #pragma unroll
@@ -805,16 +806,32 @@ __global__ __launch_bounds__(256) void k_upsample2x_bwd(const T* g, T* dst, int 
     Vec8<T> o;
 #pragma unroll
     for (int k = 0; k < 8; ++k) o.v[k] = 0.f;
-    for (int a = 0; a < ny; ++a)
-        for (int b = 0; b < nx; ++b) {
-            float acc[8];
+    // Ring copies fold only onto the two outermost rows / columns of the fine grid (pad_lo / pad_hi of every padding mode lie there):
+    // away from them -- almost every output -- the taps are plain loads, in the same order and with the same arithmetic as below
+    const int H2 = 2 * h, W2 = 2 * w;
+    const bool inner = !fold || pm == FNET_PAD_ZEROS || (2 * i - 1 >= 2 && 2 * i + 2 <= H2 - 3 && 2 * j - 1 >= 2 && 2 * j + 2 <= W2 - 3);
+    if (inner) {
+        const T* gi = g + (size_t)n * (H2 + 2) * (W2 + 2) * ldc_g + coff_g + c0;
+        for (int a = 0; a < ny; ++a)
+            for (int b = 0; b < nx; ++b) {
+                Vec8<T> v;
+                v.load(gi + ((size_t)(Ys[a] + 1) * (W2 + 2) + Xs[b] + 1) * ldc_g);
+                const float ww = wy[a] * wx[b];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) acc[k] = 0.f;
-            fold_read8<T>(g + coff_g + c0, n, Ys[a], Xs[b], 2 * h, 2 * w, ldc_g, pm, fold, acc);
-            const float ww = wy[a] * wx[b];
+                for (int k = 0; k < 8; ++k) o.v[k] += ww * (0.f + v.v[k]);
+            }
+    } else {
+        for (int a = 0; a < ny; ++a)
+            for (int b = 0; b < nx; ++b) {
+                float acc[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) o.v[k] += ww * acc[k];
-        }
+                for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+                fold_read8<T>(g + coff_g + c0, n, Ys[a], Xs[b], 2 * h, 2 * w, ldc_g, pm, fold, acc);
+                const float ww = wy[a] * wx[b];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) o.v[k] += ww * acc[k];
+            }
+    }
     o.store(dst + (((size_t)n * hp + i + 1) * wp + j + 1) * ldc_d + coff_d + c0);
 }
 

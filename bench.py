@@ -47,6 +47,7 @@ PUBLISHED_B1_128_FPS = {"medium": 200.0, "small": 1000.0}
 
 
 def arch_cfg(arch, dropout=None, depth=None):
+    act = os.environ.get("FNET_BENCH_ACT")              # development knob (activation cost studies); the headline is the architecture's own
     kw = dict(in_channels=6, out_channels=3, base_channels=32, depth=3, norm="instance", act="gelu", dropout=0.1, upsample="bilinear",
               downsample="stride", padding_mode="replicate", use_residual=True, bottleneck_blocks=1, output_activation="linear_clamp")
     kw.update(ARCHS[arch])
@@ -54,6 +55,8 @@ def arch_cfg(arch, dropout=None, depth=None):
         kw["dropout"] = dropout
     if depth is not None:
         kw["depth"] = depth
+    if act:
+        kw["act"] = act
     return UNetConfig(**kw)
 
 

@@ -30,6 +30,7 @@ class Buf:
     external: bool = False         # bound by the caller (params, inputs, outputs)
     tensor: object = None
     rc: int = 0                    # refcount for pooled temporaries
+    parent: object = None          # (Buf, element offset): this buffer is a slice of another one (allocate() makes it a view)
 
     @property
     def numel(self) -> int:
@@ -327,6 +328,17 @@ class PlanBuilder:
                     Wf=self.new_buf(f"Wf/{name}", (9, rows, kf), "T"),
                     Wd=self.new_buf(f"Wd/{name}", (9, ci, kd), "T"),
                     dWk=self.new_buf(f"dWk/{name}", (9, rows, ci), "f32"))
+        self._pack_dwk()
+
+    def _pack_dwk(self) -> None:
+        """All weight-gradient accumulators live in one slab (each 32-B aligned): one ZERO per step instead of one per conv."""
+        off = 0
+        for c in self.convs.values():
+            c["dWk"].parent = off
+            off += (c["dWk"].numel + 7) // 8 * 8
+        self.dwk_slab = self.new_buf("dWk_slab", (off,), "f32")
+        for c in self.convs.values():
+            c["dWk"].parent = (self.dwk_slab, c["dWk"].parent)
 
     # -------------------------------------------------------------------------------------------- buffers
     def new_buf(self, name, shape, kind, external=False) -> Buf:
@@ -778,8 +790,7 @@ class PlanBuilder:
 
     def emit_zero_grads(self, ops) -> None:
         self.emit_zero(ops, self.grads)
-        for c in self.convs.values():
-            self.emit_zero(ops, c["dWk"])
+        self.emit_zero(ops, self.dwk_slab)
 
     def emit_unprep(self, ops) -> None:
         for name, c in self.convs.items():
@@ -825,12 +836,16 @@ def allocate(pb: PlanBuilder, device) -> int:
     import torch
     total = 0
     for b in pb.bufs:
-        if b.external or b.tensor is not None:
+        if b.external or b.tensor is not None or b.parent is not None:
             continue
         b.tensor = torch.zeros(b.shape, dtype=_torch_dtype(b.kind, pb.dtype), device=device)
         total += b.tensor.numel() * b.tensor.element_size()
         if b is pb.nstate:
             pb.init_norm_state()
+    for b in pb.bufs:                      # slices of other buffers (after their parents exist)
+        if b.parent is not None and b.tensor is None:
+            par, off = b.parent
+            b.tensor = par.tensor[off:off + b.numel].view(b.shape)
         if pb.no_norm and b is pb.ones:
             b.tensor.fill_(1.0)
         if pb.no_norm and b is pb.ident_stats:

@@ -66,8 +66,7 @@ class UNetEngine:
             prep: List[OpRec] = []
             pb.emit_prep_weights(prep)
             zero: List[OpRec] = []
-            for c in pb.convs.values():
-                pb.emit_zero(zero, c["dWk"])
+            pb.emit_zero(zero, pb.dwk_slab)
             unprep: List[OpRec] = []
             for name, c in pb.convs.items():
                 pb.op(unprep, "UNPREP_WGRAD", [c["Cout"], c["Cin"], c["Cin_pad"], 1, c["Cout_pad"], c.get("tr", 0)], p=[Ref(c["dWk"]), pb.gref(name + ".weight")], tag=name)

@@ -31,7 +31,11 @@ def tol_for(buf, plan_dtype):
 def lockstep(pb, recs, device="cuda", verbose=False):
     """Returns a list of failure strings (empty = every op matched).  Buffers must be bound to CPU tensors."""
     cpu = {id(b): b.tensor for b in pb.bufs}
-    gpu = {id(b): b.tensor.to(device) for b in pb.bufs}
+    gpu = {id(b): b.tensor.to(device) for b in pb.bufs if b.parent is None}
+    for b in pb.bufs:                      # slices of other buffers stay slices on the device side
+        if b.parent is not None:
+            par, off = b.parent
+            gpu[id(b)] = gpu[id(par)][off:off + b.numel].view(b.shape)
     sim = Sim(pb.dtype)
     failures = []
     for k, r in enumerate(recs):

@@ -741,6 +741,35 @@ __global__ __launch_bounds__(256) void k_bias_grad(const T* d, float* dbias, int
     }
 }
 
+// Channel-group form (C <= 1024): the C/8 groups of a pixel sit on consecutive threads, so a block reads whole pixels as contiguous
+// runs; per-thread sums meet in LDS (ds_add_f32), one global atomic per channel and block.
+template <typename T>
+__global__ __launch_bounds__(256) void k_bias_grad_cg(const T* d, float* dbias, int B, int H, int W, int C, int ldc, int coff) {
+    __shared__ float red[1024];
+    const int groups = C >> 3, ppb = kThreads / groups;        // pixels per block trip
+    const int cg = threadIdx.x % groups, pl = threadIdx.x / groups;
+    for (int i = threadIdx.x; i < C; i += kThreads) red[i] = 0.f;
+    __syncthreads();
+    const int Hp = H + 2, Wp = W + 2, HW = H * W;
+    const long long total = (long long)B * HW;
+    float s[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s[k] = 0.f;
+    if (pl < ppb) {
+        for (long long p = (long long)blockIdx.x * ppb + pl; p < total; p += (long long)gridDim.x * ppb) {
+            const int n = (int)(p / HW), r = (int)(p - (long long)n * HW), y = r / W, x = r - y * W;
+            Vec8<T> v;
+            v.load(d + (((size_t)n * Hp + y + 1) * Wp + x + 1) * ldc + coff + cg * 8);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s[k] += v.v[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) atomicAdd(&red[cg * 8 + k], s[k]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C; i += kThreads) atomicAdd(dbias + i, red[i]);
+}
+
 // ------------------------------------------------------------------ UPSAMPLE2X (nn.Upsample(scale_factor=2), unet.py:152-156)
 // bilinear, align_corners=False: out[2a] = .25 in[a-1] + .75 in[a], out[2a+1] = .75 in[a] + .25 in[a+1], edges clamped.
 __device__ __forceinline__ void up_taps(int Y, int h, int mode, int& i0, int& i1, float& w0, float& w1) {
@@ -1282,6 +1311,15 @@ int fnet_op_fold_sum(const FnetOp& op, hipStream_t st) {
 int fnet_op_bias_grad(const FnetOp& op, hipStream_t st) {
     const int B = op.i[0], H = op.i[1], W = op.i[2], C = op.i[3];
     FNET_CHECK_ARG(B > 0 && H > 0 && W > 0 && vec_ok((void*)op.p[0], op.i[4], op.i[5], C, op.dtype) && op.p[1]);
+    if (C <= 1024 && C / 8 <= kThreads) {
+        const int ppb = kThreads / (C / 8);
+        long long nb = ((long long)B * H * W + (long long)ppb * 8 - 1) / ((long long)ppb * 8);
+        if (nb > 1024) nb = 1024;
+        DISPATCH_T(op.dtype, hipLaunchKernelGGL(k_bias_grad_cg<T>, dim3((unsigned)nb), dim3(kThreads), 0, st, (const T*)op.p[0],
+                                                (float*)op.p[1], B, H, W, C, op.i[4], op.i[5]));
+        FNET_LAUNCH_CHECK();
+        return FNET_OK;
+    }
     int split = (B * H * W + kThreads * 16 - 1) / (kThreads * 16);
     if (split < 1) split = 1;
     if (split > 128) split = 128;

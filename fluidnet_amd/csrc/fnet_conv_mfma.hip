@@ -59,6 +59,13 @@ typedef const __attribute__((address_space(1))) void gbl_void_t;
 #ifndef FNET_CONV_STAMPS
 #define FNET_CONV_STAMPS 0
 #endif
+// FNET_CONV_WREG=1 (experiment, measured and not kept): the weight slab of a stage goes global -> VGPR -> ds_write_b128 instead of
+// LDS-DMA (the input run stays on DMA), on the reasoning that the kernel is bound by DMA issue and the weights are 9*TN/32 of a stage's
+// pieces.  Parity-green, but the convolutions of a K4 B64 step took 17.5 ms instead of 16.1: the wave must itself wait for the loads,
+// store and wait again before the stage barrier, where a DMA piece lands on its own.
+#ifndef FNET_CONV_WREG
+#define FNET_CONV_WREG 0
+#endif
 
 struct ConvTile {          // wave-uniform description of one (pixel tile, cout tile) work item
     long long f0;
@@ -140,7 +147,24 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_conv3x3_dma(const 
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_void_t*)(wdst + qw * 1024), 16, woff, 0, 0, 0);
         }
     };
-    const int npieces = npi + NPW;
+    constexpr bool WREG = FNET_CONV_WREG != 0 && TN <= 64;   // the 512 x 128 tile has no registers to spare (256 VGPRs)
+    const int npieces = WREG ? npi : npi + NPW;    // DMA pieces per stage
+    constexpr int WPW = (NPW + NW - 1) / NW;       // weight pieces per wave on the register path
+    static_assert(WPW <= 5, "weight pieces per wave");
+    uint4 w0 = {}, w1 = {}, w2 = {}, w3 = {}, w4 = {};
+    // (macros over five named registers, not lambdas over an array: hipcc left the array in scratch)
+#define FNET_WL1(k_, var_, T_, s_)                                                                                         \
+    if (k_ < WPW && wave + NW * k_ < NPW) {                                                                                \
+        const int row_ = (wave + NW * k_) * 32 + wrow;                                                                     \
+        const int tt_ = row_ / TN;                                                                                         \
+        int co_ = (T_).n0 + (row_ - tt_ * TN);                                                                             \
+        co_ = co_ < Cout ? co_ : Cout - 1;                                                                                 \
+        var_ = *reinterpret_cast<const uint4*>(Wk + ((((size_t)(s_) * 9 + tt_) * Cout + co_) * 16 + dh * 8));              \
+    }
+#define FNET_WLOAD(T_, s_) FNET_WL1(0, w0, T_, s_) FNET_WL1(1, w1, T_, s_) FNET_WL1(2, w2, T_, s_) FNET_WL1(3, w3, T_, s_) FNET_WL1(4, w4, T_, s_)
+#define FNET_WS1(k_, var_, buf_)                                                                                           \
+    if (k_ < WPW && wave + NW * k_ < NPW) *reinterpret_cast<uint4*>(smem + (buf_) * bufsz + (wave + NW * k_) * 1024 + lane * 16) = var_;
+#define FNET_WSTORE(buf_) FNET_WS1(0, w0, buf_) FNET_WS1(1, w1, buf_) FNET_WS1(2, w2, buf_) FNET_WS1(3, w3, buf_) FNET_WS1(4, w4, buf_)
     auto issue = [&](const ConvTile& T, int s, int buf) {
         for (int q = wave; q < npieces; q += NW) issue_piece(T, s, buf, q);
     };
@@ -178,6 +202,10 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_conv3x3_dma(const 
 #define STAMP(x)
 #endif
     issue(cur, 0, 0);
+    if (WREG) {
+        FNET_WLOAD(cur, 0)
+        FNET_WSTORE(0)
+    }
     while (true) {
         bool have_next = false;
         for (int s = 0; s < nst; ++s, ++g) {
@@ -202,6 +230,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_conv3x3_dma(const 
             const int qlim = (!last || have_next) ? npieces : 0;
 #endif
             const unsigned bb = (g & 1) ? (unsigned)bufsz : 0u;
+            if (WREG && qlim) { FNET_WLOAD(Ti, si) }      // next stage's weights: in flight for the whole tap loop, stored after it
             // fragment reads run one tap ahead of the MFMAs (two register sets, static indexing after unrolling)
             bf16x8 xb[2][2], wa[2][NT];
 #pragma unroll
@@ -234,6 +263,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_conv3x3_dma(const 
 #endif
             }
             for (int q = wave + NW * 9; q < qlim; q += NW) issue_piece(Ti, si, nbuf, q);   // wide images: more than 9 pieces per wave
+            if (WREG && qlim) { FNET_WSTORE(nbuf) }
 #if FNET_CONV_STAMPS
             STAMP(st_a);
             st_loop += st_a - st_b;
@@ -388,6 +418,10 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_conv3x3_dma(const 
     }
 #endif
 #undef STAMP
+#undef FNET_WLOAD
+#undef FNET_WSTORE
+#undef FNET_WL1
+#undef FNET_WS1
 }
 
 // ------------------------------------------------------------------------------------------- weight gradient

@@ -76,7 +76,11 @@ def test_plan_engine_matches_autograd_engine_and_oracle(tmp_path, K):
         assert set(d1) == {"mse", "divergence", "gradient", "emitter", "total"}
         assert abs(d1["total"] - losses[0]) < 2e-5 * max(1, abs(losses[0])), (engine, d1["total"], losses[0])
         assert abs(d2["total"] - losses[1]) < 2e-3 * max(1, abs(losses[1])), (engine, d2["total"], losses[1])
-    assert (outs["plan"][2] - outs["autograd"][2]).abs().max() < 2e-3       # Adam amplifies noise-level gradient elements up to lr per step
+    # Adam moves an element whose gradient is rounding noise (the conv biases in front of a norm layer: exactly zero in theory) by up to lr
+    # per step in the direction of the noise's sign, so two engines may end 2 steps x 2 lr apart there; everything else agrees closely
+    diff = (outs["plan"][2] - outs["autograd"][2]).abs()
+    assert diff.max() < 4.5e-3
+    assert (diff > 1e-4).float().mean() < 0.02, float((diff > 1e-4).float().mean())
     assert d2["total"] < d1["total"] * 1.5
 
 

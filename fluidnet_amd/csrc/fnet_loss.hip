@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256) void k_head_bwd(const float* dpred, const floa
 // so a wave reads and writes 64 / CG whole pixels as one contiguous run (16 B per lane) and a thread carries Cout x 8 weight-gradient
 // accumulators instead of Cout x Cz (the pixel-per-thread form above ran 2 blocks per CU at ~1.3 TB/s).  The three (dpred, z, pred)
 // planes are read by all CG lanes of a pixel (same address: one request).
-template <typename T, int MAXO, int CG>
+template <typename T, int MAXO, int CG, bool EXACT /* Cout == MAXO: no run-time channel-count tests in the unrolled loops */>
 __global__ __launch_bounds__(256) void k_head_bwd_cg(const float* dpred, const float* z, const float* pred, const T* act, const float* Wh, T* dact,
                                                       float* dWh, float* dbh, int B, int H, int W, int C, int ldc, int coff, int ldc_d, int coff_d,
                                                       int Cout, int outact) {
@@ -349,7 +349,7 @@ __global__ __launch_bounds__(256) void k_head_bwd_cg(const float* dpred, const f
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             gw[o][k] = 0.f;
-            w8[o][k] = (o < Cout && cg * 8 + k < C) ? Wh[o * C + cg * 8 + k] : 0.f;   // zero-padded tail channels: zero gradient
+            w8[o][k] = ((EXACT || o < Cout) && cg * 8 + k < C) ? Wh[o * C + cg * 8 + k] : 0.f;   // zero-padded tail channels: zero gradient
         }
     }
     for (long long idx = (long long)blockIdx.x * kThreads + threadIdx.x; idx < total; idx += (long long)gridDim.x * kThreads) {
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(256) void k_head_bwd_cg(const float* dpred, const f
 #pragma unroll
         for (int o = 0; o < MAXO; ++o) {
             dz[o] = 0.f;
-            if (o < Cout) {
+            if (EXACT || o < Cout) {
                 const size_t oi = ((size_t)n * Cout + o) * HW + r;
                 const float g = dpred[oi], zz = z[oi], pv = pred[oi];
                 if (outact == FNET_OUT_SIGMOID_TANH) dz[o] = (o == 0) ? g * pv * (1.f - pv) : g * (1.f - pv * pv);
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(256) void k_head_bwd_cg(const float* dpred, const f
             float acc = 0.f;
 #pragma unroll
             for (int o = 0; o < MAXO; ++o)
-                if (o < Cout) {
+                if (EXACT || o < Cout) {
                     acc += w8[o][k] * dz[o];
                     gw[o][k] += dz[o] * v.v[k];
                 }
@@ -395,7 +395,7 @@ __global__ __launch_bounds__(256) void k_head_bwd_cg(const float* dpred, const f
     const int nred = Cout * C + Cout;
 #pragma unroll
     for (int o = 0; o < MAXO; ++o) {
-        if (o < Cout) {
+        if (EXACT || o < Cout) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 float s = gw[o][k];
@@ -651,10 +651,17 @@ int fnet_op_head_bwd(const FnetOp& op, hipStream_t st) {
         if (nb > 768) nb = 768;          // every block ends in Cout * C + Cout same-address atomics: keep them few
         const size_t lds_cg = (size_t)(4 * (Cout * C + Cout)) * sizeof(float);
 #define HEAD_BWD_CG(CGN)                                                                                                   \
-    DISPATCH_T(op.dtype, hipLaunchKernelGGL((k_head_bwd_cg<T, 4, CGN>), dim3((unsigned)nb), dim3(kThreads), lds_cg, st,    \
-                                            (const float*)op.p[0], (const float*)op.p[1], (const float*)op.p[2],           \
-                                            (const T*)op.p[3], (const float*)op.p[4], (T*)op.p[5], (float*)op.p[6],        \
-                                            (float*)op.p[7], B, H, W, C, op.i[4], op.i[5], op.i[6], op.i[7], Cout, op.i[9]))
+    if (Cout == 3) {                                                                                                       \
+        DISPATCH_T(op.dtype, hipLaunchKernelGGL((k_head_bwd_cg<T, 3, CGN, true>), dim3((unsigned)nb), dim3(kThreads), lds_cg, st, \
+                                                (const float*)op.p[0], (const float*)op.p[1], (const float*)op.p[2],       \
+                                                (const T*)op.p[3], (const float*)op.p[4], (T*)op.p[5], (float*)op.p[6],    \
+                                                (float*)op.p[7], B, H, W, C, op.i[4], op.i[5], op.i[6], op.i[7], Cout, op.i[9])); \
+    } else {                                                                                                               \
+        DISPATCH_T(op.dtype, hipLaunchKernelGGL((k_head_bwd_cg<T, 4, CGN, false>), dim3((unsigned)nb), dim3(kThreads), lds_cg, st, \
+                                                (const float*)op.p[0], (const float*)op.p[1], (const float*)op.p[2],       \
+                                                (const T*)op.p[3], (const float*)op.p[4], (T*)op.p[5], (float*)op.p[6],    \
+                                                (float*)op.p[7], B, H, W, C, op.i[4], op.i[5], op.i[6], op.i[7], Cout, op.i[9])); \
+    }
         if (Cz == 8) { HEAD_BWD_CG(1); }
         else if (Cz == 16) { HEAD_BWD_CG(2); }
         else if (Cz == 32) { HEAD_BWD_CG(4); }

@@ -665,13 +665,19 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
     const size_t pair = (size_t)(co >> 5) * n_ci_panels + (ci >> 5);
     const int s0 = blockIdx.y * parts_per_group, s1 = min(nparts, s0 + parts_per_group);
     const float* p = slab + (pair * nparts + s0) * WG_PART + t * 1024 + (co & 31) * 32 + (ci & 31);
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    // a thread's partials are 36 KB apart: the kernel is a chain of load round trips, so eight are kept in flight per trip
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, a5 = 0.f, a6 = 0.f, a7 = 0.f;
     int s = s0;
+    for (; s + 8 <= s1; s += 8, p += 8 * WG_PART) {
+        const float v0 = p[0], v1 = p[WG_PART], v2 = p[2 * WG_PART], v3 = p[3 * WG_PART];
+        const float v4 = p[4 * WG_PART], v5 = p[5 * WG_PART], v6 = p[6 * WG_PART], v7 = p[7 * WG_PART];
+        a0 += v0; a1 += v1; a2 += v2; a3 += v3; a4 += v4; a5 += v5; a6 += v6; a7 += v7;
+    }
     for (; s + 4 <= s1; s += 4, p += 4 * WG_PART) {
         a0 += p[0]; a1 += p[WG_PART]; a2 += p[2 * WG_PART]; a3 += p[3 * WG_PART];
     }
     for (; s < s1; ++s, p += WG_PART) a0 += *p;
-    atomicAdd(dWk + ((size_t)t * Cout + co) * Cin_w + ci, (a0 + a1) + (a2 + a3));
+    atomicAdd(dWk + ((size_t)t * Cout + co) * Cin_w + ci, ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7)));
 }
 
 template <typename K>
@@ -808,7 +814,8 @@ int fnet_wgrad_mfma(const FnetOp& op, hipStream_t st) {
 #undef WGD_LAUNCH
         const int elems = 9 * Cout * Cin;
         const int eb = (elems + kThreads - 1) / kThreads;
-        int groups = (1024 + eb - 1) / eb;
+        static const int red_blocks = [] { const char* e = getenv("FNET_WG_RED_BLOCKS"); return e ? atoi(e) : 1024; }();
+        int groups = (red_blocks + eb - 1) / eb;
         if (groups > nparts) groups = nparts;
         const int ppg = (nparts + groups - 1) / groups;
         groups = (nparts + ppg - 1) / ppg;

@@ -642,10 +642,33 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_dma(const bf16_t* __restrict__
                 }
         }
     }
+    // KS > 1: the KS waves that split the k-steps of one panel pair add their accumulators up through LDS (lane-linear 36-KB images, one
+    // per pair, over the stage buffers) before anything goes to the slab: KS times fewer partials to write and to reduce
+    if (KS > 1) {
+        float* xch = reinterpret_cast<float*>(smem) + (size_t)(cop + NCO * cip) * WG_PART;
+#pragma unroll 1
+        for (int j = 1; j < KS; ++j) {
+            __syncthreads();                  // stage buffers (j = 1) / the previous round's image are no longer read
+            if (ksl == j) {
+#pragma unroll
+                for (int t = 0; t < 9; ++t)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) xch[(t * 16 + i) * 64 + lane] = acc[t][i];
+            }
+            __syncthreads();
+            if (ksl == 0) {
+#pragma unroll
+                for (int t = 0; t < 9; ++t)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc[t][i] += xch[(t * 16 + i) * 64 + lane];
+            }
+        }
+        if (ksl != 0) return;
+    }
     // D[row = co][col = ci]: partial[t][co][ci], lanes run along ci (two 128-B segments per store instruction)
     const int r = lane & 31, h = lane >> 5;
     const size_t pair = (size_t)(co_tile * NCO + cop) * (n_ci_tiles * NCI) + (ci_tile * NCI + cip);
-    float* part = slab + (pair * nparts + (size_t)blockIdx.x * KS + ksl) * WG_PART;
+    float* part = slab + (pair * nparts + (size_t)blockIdx.x) * WG_PART;
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
@@ -784,7 +807,6 @@ int fnet_wgrad_mfma(const FnetOp& op, hipStream_t st) {
         const int log2cw = W > 16 ? 5 : 4;
         const int CW = 1 << log2cw, CH = WG_PX / CW;
         const int nch = B * ((W + CW - 1) / CW) * ((H + CH - 1) / CH);
-        const int ks = 4 / (nco * nci);
         const int co_tiles = (Cout + 32 * nco - 1) / (32 * nco), ci_tiles = (Cin + 32 * nci - 1) / (32 * nci);
         // two blocks per CU over the whole launch
         static const int target_blocks = [] { const char* e = getenv("FNET_WG_BLOCKS"); return e ? atoi(e) : 512; }();
@@ -792,7 +814,7 @@ int fnet_wgrad_mfma(const FnetOp& op, hipStream_t st) {
         if (splits > nch) splits = nch;
         int cpb = (nch + splits - 1) / splits;
         splits = (nch + cpb - 1) / cpb;
-        const int nparts = splits * ks;
+        const int nparts = splits;               // one partial per block and panel pair (the ks waves of a pair combine in LDS)
         const long long need = (long long)co_tiles * nco * ci_tiles * nci * nparts;
         FNET_CHECK_ARG(need <= op.i[12]);
         const bf16_t* src = (const bf16_t*)op.p[0];
@@ -801,7 +823,8 @@ int fnet_wgrad_mfma(const FnetOp& op, hipStream_t st) {
         const dim3 grid(splits, co_tiles, ci_tiles);
 #define WGD_LAUNCH(A, B_)                                                                                                  \
     {                                                                                                                     \
-        const size_t lds = 2 * ((size_t)A * WG_PX * PANEL_ROW + (size_t)B_ * WG_SROWS * PANEL_ROW);                        \
+        size_t lds = 2 * ((size_t)A * WG_PX * PANEL_ROW + (size_t)B_ * WG_SROWS * PANEL_ROW);                              \
+        if (A * B_ < 4 && lds < (size_t)A * B_ * WG_PART * 4) lds = (size_t)A * B_ * WG_PART * 4;                          \
         int rc = set_lds_limit(k_wgrad_dma<A, B_>, lds);                                                                   \
         if (rc) return rc;                                                                                                \
         hipLaunchKernelGGL((k_wgrad_dma<A, B_>), grid, dim3(kThreads), lds, st, src, dout, slab, B, H, W, op.i[3], op.i[4], \

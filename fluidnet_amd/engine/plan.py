@@ -219,7 +219,8 @@ WG_PART = 9 * 32 * 32          # floats per wave partial of the weight-gradient 
 
 def wgrad_slab_parts(cfg) -> int:
     """Upper bound of (co panels x ci panels x pixel splits x k-split waves) over the layers of `cfg`, mirroring the launch
-    geometry of fnet_wgrad_mfma: ~512 blocks per launch, 4 waves each."""
+    geometry of fnet_wgrad_mfma: ~512 blocks per launch, 4 waves each.  (The k-split waves of a panel pair now combine in LDS and write one
+    partial per block and pair, so the last factor makes this a 1-4x over-estimate: kept as a safe upper bound.)"""
     worst = 0
     for k, s in unet_param_shapes(cfg).items():
         if len(s) == 4 and s[2] in (2, 3):

@@ -144,12 +144,16 @@ def profile_ops(plan_arrays, recs_by_section, dump_path=None):
         recs = recs_by_section[name]
         for k in range(len(arr)):
             t = tm[0]
+            one = arr[k:k + 1].copy()
+            one["i"][:, rt.LANE_SLOT] = 0          # per-op timing: side-lane launches are timed on the caller's stream too
             t.start()
-            rt.run_ops(arr[k:k + 1])
+            rt.run_ops(one)
             t.stop()
             ms = max(t.elapsed_ms() - overhead, 0.0)
             r = recs[k]
             kind = rt.OPNAME[r.code]
+            if kind.startswith("EVENT_"):          # lane bookkeeping, not a kernel
+                continue
             rows.append((name, k, kind, r.tag, ms, r.flops, list(r.i[:12])))
             if kind == "CONV3X3":
                 kind = "CONV3X3_" + ("MFMA" if r.i[8] == rt.CONV_MFMA else "REF")

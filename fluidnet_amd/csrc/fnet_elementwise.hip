@@ -1273,11 +1273,11 @@ int fnet_op_affine_grad(const FnetOp& op, hipStream_t st) {
     return FNET_OK;
 }
 
-// AFFINE_GRAD_MULTI  i: 0 B,1 n_units (<= 7), per unit u at 2+4u: S offset (floats),C,dgamma offset,dbeta offset (floats)
+// AFFINE_GRAD_MULTI  i: 0 B,1 n_units (<= 6), per unit u at 2+4u: S offset (floats),C,dgamma offset,dbeta offset (floats)
 //                    p: 0 S slab base,1 flat gradient buffer (+=)
 int fnet_op_affine_grad_multi(const FnetOp& op, hipStream_t st) {
     const int B = op.i[0], n = op.i[1];
-    FNET_CHECK_ARG(B > 0 && n >= 1 && n <= 7 && op.p[0] && op.p[1] && (op.p[0] % 8) == 0);
+    FNET_CHECK_ARG(B > 0 && n >= 1 && n <= 6 && op.p[0] && op.p[1] && (op.p[0] % 8) == 0);
     AffineUnits u;
     u.n = n;
     int cmax = 0;

@@ -1,5 +1,6 @@
 // Plan executor, hipGraph capture/replay, HIP-event timers: the native runtime under the Python host mirror.
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "fnet_common.h"
 
@@ -45,6 +46,52 @@ static int dispatch_op(const FnetOp& op, hipStream_t st) {
         case FNET_OP_STENCIL: return fnet_op_stencil(op, st);
         default: return FNET_E_BADARG;
     }
+}
+
+// ---- lanes: a plan may spread its ops over the caller's stream (lane 0) and up to FNET_MAX_LANES-1 library-owned side streams.
+// An op's lane is op.i[FNET_LANE_SLOT]; EVENT_RECORD / EVENT_WAIT order lanes against each other (hipEventRecord on the op's lane,
+// hipStreamWaitEvent of the op's lane on that event).  The plan builder is responsible for joining every side lane back into
+// lane 0 before the plan ends (and before anything reuses a buffer a side lane still reads).  Streams and events are created
+// lazily, once per device and process, and never destroyed (a few hundred bytes each).
+#define FNET_MAX_DEVICES 16
+static hipStream_t g_lane_stream[FNET_MAX_DEVICES][FNET_MAX_LANES];
+static hipEvent_t* g_events[FNET_MAX_DEVICES];
+static int g_n_events[FNET_MAX_DEVICES];
+
+static int lane_stream(int lane, hipStream_t caller, hipStream_t* out) {
+    if (lane == 0) { *out = caller; return FNET_OK; }
+    if (lane < 0 || lane >= FNET_MAX_LANES) return FNET_E_BADARG;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess || dev < 0 || dev >= FNET_MAX_DEVICES) { g_fnet_last_hip_error = (int)e; return FNET_E_HIP; }
+    if (!g_lane_stream[dev][lane]) {
+        e = hipStreamCreateWithFlags(&g_lane_stream[dev][lane], hipStreamNonBlocking);
+        if (e != hipSuccess) { g_fnet_last_hip_error = (int)e; return FNET_E_HIP; }
+    }
+    *out = g_lane_stream[dev][lane];
+    return FNET_OK;
+}
+
+static int plan_event(int id, hipEvent_t* out) {
+    if (id < 0 || id >= (1 << 20)) return FNET_E_BADARG;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess || dev < 0 || dev >= FNET_MAX_DEVICES) { g_fnet_last_hip_error = (int)e; return FNET_E_HIP; }
+    if (id >= g_n_events[dev]) {
+        int n = g_n_events[dev] ? g_n_events[dev] : 256;
+        while (n <= id) n *= 2;
+        hipEvent_t* p = (hipEvent_t*)realloc(g_events[dev], sizeof(hipEvent_t) * n);
+        if (!p) return FNET_E_HIP;
+        for (int k = g_n_events[dev]; k < n; ++k) p[k] = nullptr;
+        g_events[dev] = p;
+        g_n_events[dev] = n;
+    }
+    if (!g_events[dev][id]) {
+        e = hipEventCreateWithFlags(&g_events[dev][id], hipEventDisableTiming);
+        if (e != hipSuccess) { g_fnet_last_hip_error = (int)e; return FNET_E_HIP; }
+    }
+    *out = g_events[dev][id];
+    return FNET_OK;
 }
 
 struct FnetGraph {
@@ -94,9 +141,22 @@ int fnet_device_info(int32_t out[4]) {
 
 int fnet_plan_run(const FnetOp* ops, int32_t n_ops, void* stream, int32_t* failed_index) {
     if (!ops || n_ops < 0) return FNET_E_BADARG;
-    hipStream_t st = (hipStream_t)stream;
+    hipStream_t caller = (hipStream_t)stream;
     for (int32_t k = 0; k < n_ops; ++k) {
-        const int rc = dispatch_op(ops[k], st);
+        hipStream_t st = caller;
+        int rc = lane_stream(ops[k].i[FNET_LANE_SLOT], caller, &st);
+        if (rc == FNET_OK) {
+            if (ops[k].op == FNET_OP_EVENT_RECORD || ops[k].op == FNET_OP_EVENT_WAIT) {
+                hipEvent_t ev = nullptr;
+                rc = plan_event(ops[k].i[0], &ev);
+                if (rc == FNET_OK) {
+                    const hipError_t e = ops[k].op == FNET_OP_EVENT_RECORD ? hipEventRecord(ev, st) : hipStreamWaitEvent(st, ev, 0);
+                    if (e != hipSuccess) { g_fnet_last_hip_error = (int)e; rc = FNET_E_HIP; }
+                }
+            } else {
+                rc = dispatch_op(ops[k], st);
+            }
+        }
         if (rc != FNET_OK) {
             if (failed_index) *failed_index = k;
             return rc;

@@ -148,7 +148,8 @@ PV unit(Rollout& r, const std::string& conv, const std::string& norm, const PV& 
     if (r.cfg.norm != 0) {
         FnetOp s = mkop(FNET_OP_NORM_COMBINE);
         const int batch = r.cfg.norm == 1;
-        const int v[5] = {r.B, cout, batch ? 3 : 2, batch ? 1 : group_size(r.cfg.group_norm_groups, cout), raw.H * raw.W};
+        // groups are formed over the layer's REAL channels (ce.cout); `cout` may be the zero-padded count (base_channels % 8 != 0)
+        const int v[6] = {r.B, cout, batch ? 3 : 2, batch ? 1 : group_size(r.cfg.group_norm_groups, ce.cout), raw.H * raw.W, ce.cout};
         memcpy(s.i, v, sizeof(v));
         s.f[0] = 1e-5f; s.f[1] = 0.1f;
         s.p[0] = (uint64_t)st;

@@ -13,6 +13,7 @@ Data parallel: rank r of `world` takes rows [r*B, (r+1)*B) of every global batch
 """
 from __future__ import annotations
 
+import contextlib
 from typing import Iterator, List, Optional, Tuple
 
 import numpy as np
@@ -74,6 +75,10 @@ class HbmBatchLoader:
         self.Km = mask_frames if mask_frames is not None else self.K
         if self.Km not in (self.K, self.K + 1):
             raise ValueError("mask_frames must be K or K+1")
+        # first mask frame relative to t: the on-disk convention (K+1 frames) starts at t, the preloaded one (K frames) at t+1; a
+        # single-step dataset (rollout_steps == 1) has no mask tensor at all: its masks are channels 4,5 of x, i.e. frame t
+        # (npz_sequence.py:144-153, trainer.py:187-188), so a K = 1 plan fed from here must see frame t as well
+        self.mask_first = 0 if (ds.rollout_steps <= 1 or self.Km == self.K + 1) else 1
         self.flip_p = ds.flip_probability if (ds.is_training and ds.enable_augmentation) else 0.0
         self.epoch = 0
         dev = store.frames.device
@@ -112,14 +117,17 @@ class HbmBatchLoader:
         for t_, shp in ((x0, (B, 6, st.H, st.W)), (y, (B, self.K, 3, st.H, st.W)), (masks, (B, self.Km, 2, st.H, st.W))):
             if tuple(t_.shape) != shp or t_.dtype != torch.float32 or not t_.is_contiguous() or t_.device != st.frames.device:
                 raise ValueError(f"output buffer must be contiguous fp32 {shp} on {st.frames.device}, got {tuple(t_.shape)} {t_.dtype}")
-        self._idx[:B].copy_(torch.from_numpy(st.frame_index(rows)), non_blocking=True)
-        self._flip[:B].copy_(torch.from_numpy(np.ascontiguousarray(flips, dtype=np.int32)), non_blocking=True)
         ops = np.zeros(1, dtype=rt.OP_DTYPE)
         o = ops[0]
         o["op"] = rt.OPC["GATHER_BATCH"]
-        o["i"][:7] = [B, st.H, st.W, self.K, self.Km, 1 if self.Km == self.K else 0, st.t_total]
+        o["i"][:7] = [B, st.H, st.W, self.K, self.Km, self.mask_first, st.t_total]
         o["p"][:6] = [st.frames.data_ptr(), self._idx.data_ptr(), self._flip.data_ptr(), x0.data_ptr(), y.data_ptr(), masks.data_ptr()]
-        rt.run_ops(ops, stream)
+        # the index / flag uploads and the kernel go to ONE stream (the reused index buffers would otherwise race)
+        ctx = torch.cuda.stream(torch.cuda.ExternalStream(stream)) if stream is not None else contextlib.nullcontext()
+        with ctx:
+            self._idx[:B].copy_(torch.from_numpy(st.frame_index(rows)), non_blocking=True)
+            self._flip[:B].copy_(torch.from_numpy(np.ascontiguousarray(flips, dtype=np.int32)), non_blocking=True)
+            rt.run_ops(ops, stream)
 
     def __iter__(self) -> Iterator[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]]:
         """DataLoader-style iteration (fresh tensors per batch) for code that wants tuples; the zero-copy way is gather() into a

@@ -6,8 +6,9 @@ t in range(1 + offset, T - rollout_steps, stride) (:68-75); set_epoch rotates th
 rollout_steps == 1 -> (x[6,H,W], y[3,H,W]) with x = [d_t, vx_t, vz_t, d_{t-1}, emitter_t, collider_t], y = state_{t+1};
 rollout_steps  > 1 -> (x_0[6], y_seq[K,3], masks): NOTE the two mask conventions of the reference are kept exactly --
 the on-disk path returns K+1 mask frames t..t+K (:185,:200,:210), the preloaded path K frames t+1..t+K (:406,:421).
-Host-side numpy only (no kernel); parity is "unpinned" by the reference (its dataset module needs pydantic_settings,
-absent here) and is checked against the oracle's independent restatement in tests/test_dataset.py.
+Host-side numpy only (no kernel).  Pinned to the reference by the g6 fixtures: tuples, index lists, epoch offsets, normalisation and
+flipped samples produced by the REAL ml/dataset module for the files of tests/fixture_inputs.py (tests/golden/make_golden.py imports it
+with a pydantic_settings stub; tests/test_golden_next_rows.py compares bit for bit), plus the oracle's restatement in tests/test_dataset.py.
 Differences from the reference: `norm_scales` / `stats_path` can be passed explicitly instead of being read from the
 project config; preloading never prints.
 """

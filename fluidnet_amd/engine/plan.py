@@ -83,6 +83,7 @@ class OpRec:
     dtype: int = 0
     tag: str = ""
     flops: float = 0.0             # algorithmic (useful) FLOPs of this launch, for roofline accounting
+    lane: int = 0                  # 0 = the caller's stream, 1.. = a side stream of the library (fluidnet_hip.h "Lanes")
 
 
 @dataclass(eq=False)
@@ -272,6 +273,15 @@ class PlanBuilder:
         self.conv_impl = conv_impl
         self.training = training
         self.seed = seed & 0x7FFFFFFF
+        # Lanes: the weight-gradient launches of a backward pass go to side stream `wgrad_lane` (0 = keep everything on the caller's
+        # stream).  Nothing on the data-gradient chain depends on them, and they are MFMA-bound where the normalisation / activation
+        # adjoint kernels that follow on lane 0 are HBM- and VALU-bound, so the two overlap.  Buffers a side-lane launch reads are
+        # held back from the temporary pool until the lanes are joined (emit_side_join, once per backward pass).
+        self.wgrad_lane = int(os.environ.get("FNET_WGRAD_LANE", "0")) if (training and dtype == "bf16") else 0
+        self._n_events = 0
+        self._side_reads: set = set()
+        self._side_held: List[Buf] = []
+        self._side_dirty = False
         self.pm = rt.PAD[cfg.padding_mode]
         self.act = rt.ACT[cfg.act]
         self.bufs: List[Buf] = []
@@ -367,7 +377,30 @@ class PlanBuilder:
         b.rc -= 1
         assert b.rc >= 0, b.name
         if b.rc == 0:
+            if id(b) in self._side_reads:       # a side lane may still be reading it: back to the pool at the next join
+                self._side_held.append(b)
+            else:
+                self.pool[(b.shape[1] - 2, b.shape[2] - 2, b.shape[3])].append(b)
+
+    def new_event(self) -> int:
+        self._n_events += 1
+        return self._n_events - 1
+
+    def emit_lane_edge(self, ops, src_lane: int, dst_lane: int) -> None:
+        """Everything issued so far on src_lane happens before whatever dst_lane is given next."""
+        ev = self.new_event()
+        self.op(ops, "EVENT_RECORD", [ev], lane=src_lane)
+        self.op(ops, "EVENT_WAIT", [ev], lane=dst_lane)
+
+    def emit_side_join(self, ops) -> None:
+        """Lane 0 waits for the side lane; the temporaries it was reading return to the pool."""
+        if self._side_dirty:
+            self.emit_lane_edge(ops, self.wgrad_lane, 0)
+            self._side_dirty = False
+        for b in self._side_held:
+            self._side_reads.discard(id(b))
             self.pool[(b.shape[1] - 2, b.shape[2] - 2, b.shape[3])].append(b)
+        self._side_held = []
 
     def s_alloc(self, n: int) -> Ref:
         """n floats of the S slab (per-(n,c) backward sums of the InstanceNorm adjoint)."""
@@ -419,8 +452,8 @@ class PlanBuilder:
         return rt.CONV_MFMA if ok else rt.CONV_REF
 
     # -------------------------------------------------------------------------------------------- op emitters
-    def op(self, ops, code, i, f=(), p=(), tag="") -> None:
-        ops.append(OpRec(OPC[code], [int(v) for v in i], [float(v) for v in f], list(p), self.dtype, tag))
+    def op(self, ops, code, i, f=(), p=(), tag="", lane: int = 0) -> None:
+        ops.append(OpRec(OPC[code], [int(v) for v in i], [float(v) for v in f], list(p), self.dtype, tag, lane=lane))
 
     def e_pack(self, ops, planes, dst: Buf):
         """planes: six (Ref, batch stride) field planes (the rollout's channels), or ("nchw", Ref, n): one contiguous [B,n,H,W] tensor
@@ -467,9 +500,17 @@ class PlanBuilder:
         c = self.convs[conv]
         npix = self.B * (src.H + 2) * (src.W + 2)
         assert src.C == c["Cin_pad"] and dout.C == c["Cout_pad"], (conv, src.C, dout.C)
+        lane = self.wgrad_lane
+        if lane:
+            # all weight gradients share one lane: the partial slab and the dWk accumulators are touched in stream order there
+            self.emit_lane_edge(ops, 0, lane)
+            self._side_dirty = True
+            for b in (src.buf, dout.buf):
+                if b.name.startswith("tmp/"):
+                    self._side_reads.add(id(b))
         self.op(ops, "WGRAD", [npix, src.W + 2, src.C, src.ldc, src.coff, dout.C, dout.ldc, dout.coff,
                                self.impl_for(src.C, dout.C), c["Cin_pad"], self.B, src.H, self.wgrad_slab.numel // WG_PART],
-                p=[src.ref, dout.ref, Ref(c["dWk"]), Ref(self.wgrad_slab)], tag=conv)
+                p=[src.ref, dout.ref, Ref(c["dWk"]), Ref(self.wgrad_slab)], tag=conv, lane=lane)
         ops[-1].flops = self.conv_flops(conv, src.H, src.W)
 
     def e_stats(self, ops, raw: PV, st: Buf, from_conv: bool = False):
@@ -694,10 +735,10 @@ class PlanBuilder:
         return dx
 
     def flush_affine(self, ops) -> None:
-        """AFFINE_GRAD of every unit visited since the last flush, 7 per launch (their S sums all live in the current slab)."""
+        """AFFINE_GRAD of every unit visited since the last flush, 6 per launch (their S sums all live in the current slab)."""
         pend, self._affine_pending = self._affine_pending, []
-        for k in range(0, len(pend), 7):
-            grp = pend[k:k + 7]
+        for k in range(0, len(pend), 6):
+            grp = pend[k:k + 6]
             iv = [self.B, len(grp)]
             for (S, C, gw, gb, _) in grp:
                 assert S.buf is self.s_slab and (gw is None or gw.buf is self.grads) and gb.buf is self.grads
@@ -771,6 +812,7 @@ class PlanBuilder:
             self.op(ops, "UNPACK_GRAD", [B, H, W, 16, dx_channels, self.pm], p=[g.pv.ref, Ref(dx_out)], tag="dx")
             self.release(g.pv.buf)
         self.flush_affine(ops)
+        self.emit_side_join(ops)
         if self.s_slab is not None and self.s_slab.shape[0] > s_begin:
             nbytes = (self.s_slab.shape[0] - s_begin) * 4
             z = OpRec(OPC["ZERO"], [nbytes & 0x7FFFFFFF, nbytes >> 31], [], [Ref(self.s_slab, s_begin)], self.dtype, "S_slab")
@@ -861,8 +903,9 @@ def lower(pb: PlanBuilder, recs: List[OpRec]) -> np.ndarray:
         a = arr[k]
         a["op"] = r.code
         a["dtype"] = r.dtype
-        assert len(r.i) <= 30 and len(r.f) <= 8 and len(r.p) <= 10, r
+        assert len(r.i) <= rt.LANE_SLOT and len(r.f) <= 8 and len(r.p) <= 10, r
         a["i"][: len(r.i)] = r.i
+        a["i"][rt.LANE_SLOT] = r.lane
         a["f"][: len(r.f)] = r.f
         for j, ref in enumerate(r.p):
             if ref is None:

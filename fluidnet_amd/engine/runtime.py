@@ -26,7 +26,9 @@ OPC = dict(NOP=0, PACK_INPUT=1, CONV3X3=2, WGRAD=3, IN_STATS=4, APPLY=5, UPSAMPL
            HEAD_FWD=9, LOSS_REDUCE=10, LOSS_FINALIZE=11, LOSS_GRAD=12, HEAD_BWD=13, INACT_BWD_REDUCE=14,
            INACT_BWD_APPLY=15, AFFINE_GRAD=16, FOLD_SUM=17, BIAS_GRAD=18, ZERO_INSERT=19, UPSAMPLE2X_BWD=20,
            UNPACK_GRAD=21, ZERO=22, PREP_WEIGHTS=23, GRAD_NORM=24, ADAM=25, COPY_PLANES=26, UNPREP_WGRAD=27, STENCIL=28,
-           AFFINE_GRAD_MULTI=29, METRICS=30, GATHER_BATCH=31, POOL2X=32, POOL2X_BWD=33, NORM_COMBINE=34, NORM_COMBINE_BWD=35, DEPTH2SPACE=36, SPACE2DEPTH=37)
+           AFFINE_GRAD_MULTI=29, METRICS=30, GATHER_BATCH=31, POOL2X=32, POOL2X_BWD=33, NORM_COMBINE=34, NORM_COMBINE_BWD=35, DEPTH2SPACE=36, SPACE2DEPTH=37,
+           EVENT_RECORD=38, EVENT_WAIT=39)
+LANE_SLOT = 29        # FnetOp.i[29]: the lane (stream) an op runs on; include/fluidnet_hip.h FNET_LANE_SLOT
 OPNAME = {v: k for k, v in OPC.items()}
 
 

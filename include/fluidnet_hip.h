@@ -117,8 +117,18 @@ enum FnetOpCode {
     FNET_OP_NORM_COMBINE_BWD = 35,
     FNET_OP_DEPTH2SPACE = 36,     /* phase interleave + bias of the transposed-conv upsample (unet.py:150) */
     FNET_OP_SPACE2DEPTH = 37,
+    FNET_OP_EVENT_RECORD = 38,    /* lanes: record event i[0] on the op's lane (see FNET_LANE_SLOT) */
+    FNET_OP_EVENT_WAIT = 39,      /* lanes: the op's lane waits for the last record of event i[0] */
     FNET_OP_COUNT_
 };
+
+/* Lanes.  Every op runs on lane op.i[FNET_LANE_SLOT]: lane 0 is the stream passed to fnet_plan_run, lanes 1..FNET_MAX_LANES-1 are
+ * side streams the library creates once per device (hipStreamNonBlocking).  EVENT_RECORD / EVENT_WAIT (event ids 0 .. 2^20-1, a
+ * per-device pool shared by all plans: an id is recorded before it is waited for inside one fnet_plan_run) order lanes against
+ * each other.  The plan builder joins every side lane back into lane 0 before the plan ends.  Used to run the weight-gradient
+ * kernels (MFMA-bound) beside the normalisation / activation adjoint kernels (HBM- and VALU-bound) of the backward pass. */
+#define FNET_LANE_SLOT 29
+#define FNET_MAX_LANES 4
 
 /* Library identity / diagnostics. */
 int fnet_abi_version(void);

@@ -90,8 +90,8 @@
  * NORM_COMBINE_BWD  i: 0 B, 1 C, 2 kind, 3 channels per group, 4 real C (0 = C); p: 0 S float2[B][C], 1 gamma, 2 Sw float2[B][C] out: the
  *                      gamma-weighted mean of S over the normalisation group (kind 3: zeros), read by INACT_BWD_APPLY with i[15] = 1
  * AFFINE_GRAD       i: 0 B, 1 C; p: 0 S float2[B][C], 1 dgamma (+=), 2 dbeta (+=)
- * AFFINE_GRAD_MULTI AFFINE_GRAD of up to 7 norm layers in one launch (the plan batches a backward pass's 26 layers into 4)
- *   i: 0 B, 1 n_units (<= 7), then per unit u at 2+4u: S offset (floats from p[0]), C, dgamma offset (-1: none), dbeta offset
+ * AFFINE_GRAD_MULTI AFFINE_GRAD of up to 6 norm layers in one launch (the plan batches a backward pass's 26 layers into 5; slot 29 is the lane)
+ *   i: 0 B, 1 n_units (<= 6), then per unit u at 2+4u: S offset (floats from p[0]), C, dgamma offset (-1: none), dbeta offset
  *      (floats from p[1])
  *   p: 0 S slab base, 1 flat gradient buffer base (+=)
  * FOLD_SUM          i: 0 B, 1 H, 2 W, 3 C, 4 ldc_g1, 5 coff_g1, 6 ldc_g2, 7 coff_g2, 8 ldc_d, 9 coff_d, 10 fold1, 11 fold2, 12 pm

@@ -9,8 +9,12 @@ synth_batch), so the fixtures store expected OUTPUTS plus small inputs; nothing 
 source is stored.  Importable reference pieces: models.unet (UNet, UNetConfig) and
 training.physics_loss (everything).  training.trainer needs mlflow/torchmetrics (absent), so the
 K-step rollout loss is pinned by composing the reference UNet + reference PhysicsAwareLoss in the
-loop shape of trainer.py:355-385 below.  dataset.* needs pydantic_settings (absent) -> the dataset
-layout stays "parity unpinned" (restated from the text of npz_sequence.py).
+loop shape of trainer.py:355-385 below.
+Round 2 additions: dataset.* imports config.config -> pydantic_settings (absent): a stub module
+(BaseSettings = pydantic.BaseModel, SettingsConfigDict = dict) in sys.modules lets the REAL dataset module import -> g6;
+scripts.variant_manager needs only yaml -> g9; training.metrics imports torchmetrics (absent) for SSIM only: a stub
+torchmetrics.functional.image module lets its seven other functions import -> g10 (SSIM itself stays unpinned).
+Their seeded inputs come from tests/fixture_inputs.py (our code), shared with the tests.
 """
 import os
 import sys
@@ -19,6 +23,7 @@ sys.dont_write_bytecode = True
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, "/root/reference/ml")
 
 import numpy as np  # noqa: E402
@@ -279,7 +284,148 @@ def g8():
     save("g8_rollout16.npz", frames=np.stack(outs), emitter=em, collider=co)
 
 
+# ---------------------------------------------------------------- G6: dataset tuples + augmentation from the real dataset module
+def _stub_pydantic_settings():
+    import types
+
+    import pydantic
+    if "pydantic_settings" not in sys.modules:
+        st = types.ModuleType("pydantic_settings")
+        st.BaseSettings = pydantic.BaseModel
+        st.SettingsConfigDict = dict
+        sys.modules["pydantic_settings"] = st
+
+
+def g6():
+    import tempfile
+    from pathlib import Path
+
+    import fixture_inputs as fi
+    _stub_pydantic_settings()
+    from dataset import npz_sequence as ref_ds           # reference
+    from dataset import augmentations as ref_aug         # reference
+    arrs = {}
+    with tempfile.TemporaryDirectory() as td:
+        root = fi.write_synth_npz(Path(td))
+        for K in (1, 4):
+            for preload in (False, True):
+                for stride in (1, 3):
+                    ds = ref_ds.FluidNPZSequenceDataset(root, "train", rollout_steps=K, preload=preload, stride=stride)
+                    pre = f"K{K}/pre{int(preload)}/s{stride}"
+                    arrs[f"{pre}/len"] = np.int64(len(ds))
+                    arrs[f"{pre}/index0"] = np.array(ds._index, np.int64)
+                    ds.set_epoch(1)
+                    arrs[f"{pre}/index1"] = np.array(ds._index, np.int64)
+                    ds.set_epoch(0)
+                    for idx in (0, len(ds) // 2, len(ds) - 1):
+                        for j, t in enumerate(ds[idx]):
+                            arrs[f"{pre}/item{idx}/{j}"] = t
+        ds = ref_ds.FluidNPZSequenceDataset(root, "val", rollout_steps=2, preload=True)      # the file without masks
+        for j, t in enumerate(ds[1]):
+            arrs[f"val_nomask/K2/item1/{j}"] = t
+        ds = ref_ds.FluidNPZSequenceDataset(root, "val", rollout_steps=1, preload=False)
+        for j, t in enumerate(ds[2]):
+            arrs[f"val_nomask/K1/item2/{j}"] = t
+        # normalisation through the module-level loaders (the class would read <project>/data/_field_stats.yaml, absent)
+        p0 = sorted((root / "train").iterdir())[0]
+        for j, t in enumerate(ref_ds._load_sample(p0, 3, True, fi.G6_SCALES)):
+            arrs[f"norm/single/{j}"] = t
+        for j, t in enumerate(ref_ds._load_rollout_sample(p0, 2, 4, True, fi.G6_SCALES)):
+            arrs[f"norm/rollout/{j}"] = t
+        # preloaded + normalised: the in-memory path with the scales injected after construction
+        ds = ref_ds.FluidNPZSequenceDataset(root, "train", rollout_steps=4, preload=True)
+        ds.normalize, ds._norm_scales = True, dict(fi.G6_SCALES)
+        for j, t in enumerate(ds[1]):
+            arrs[f"norm/preloaded_rollout/{j}"] = t
+        # flip augmentation forced on / off (augmentations.py:14-35)
+        ds1 = ref_ds.FluidNPZSequenceDataset(root, "train", rollout_steps=1, preload=True)
+        ds4 = ref_ds.FluidNPZSequenceDataset(root, "train", rollout_steps=4, preload=False)
+        x, y = ds1[2]
+        for tag, p in (("on", 1.0), ("off", 0.0)):
+            fx, fy = ref_aug.apply_augmentation(x.clone(), y.clone(), p)
+            arrs[f"flip_{tag}/single/0"], arrs[f"flip_{tag}/single/1"] = fx, fy
+            x0, ys, mk = ds4[2]
+            for j, t in enumerate(ref_aug.apply_rollout_augmentation(x0.clone(), ys.clone(), mk.clone(), p)):
+                arrs[f"flip_{tag}/rollout/{j}"] = t
+    save("g6_dataset.npz", **arrs)
+
+
+# ---------------------------------------------------------------- G9: VariantManager (curriculum configuration plumbing)
+def g9():
+    import json
+    import tempfile
+    from pathlib import Path
+
+    import fixture_inputs as fi
+    from scripts.variant_manager import VariantManager   # reference
+
+    def dump_tree(cfg_root, ck_root):
+        m = VariantManager(Path(cfg_root), Path(ck_root))
+        names = sorted(m._variants_cache)
+        out = {"variants": names, "configs": {}, "chains": {}, "parents": {}, "relative_dirs": {}, "warmstart": {}}
+        for n in names:
+            cfg = m.build_config_with_inheritance(n)
+            out["configs"][n] = json.loads(json.dumps(cfg, default=str))
+            out["chains"][n] = m.resolve_dependency_chain(n)
+            out["parents"][n] = m.get_parent_variant(n)
+            out["relative_dirs"][n] = str(m.get_variant_relative_dir(n))
+            try:
+                w = m.get_warmstart_checkpoint(n)
+            except FileNotFoundError as e:      # no parent checkpoint on disk: the path it looked for is in the message
+                w = str(e).split("Parent checkpoint not found: ")[1].split("\n")[0]
+            out["warmstart"][n] = None if w is None else str(Path(w).relative_to(ck_root))
+        out["topo_all"] = m.topological_sort(names)
+        out["topo_reversed"] = m.topological_sort(list(reversed(names)))
+        return out
+
+    res = {}
+    with tempfile.TemporaryDirectory() as td:
+        res["synthetic"] = dump_tree(fi.write_synth_config_tree(Path(td)), Path(td) / "ck")
+        res["synthetic_topo_subset"] = VariantManager(Path(td) / "config", Path(td) / "ck").topological_sort(["A-K4", "B-solo"])
+    # the reference's own configuration tree (the test that reads it only runs where /root/reference exists)
+    res["reference_tree"] = dump_tree("/root/reference/ml/config", "/tmp/ck_root")
+    path = os.path.join(HERE, "g9_variants.json")
+    with open(path, "w") as f:
+        json.dump(res, f, indent=1, sort_keys=True)
+    print(f"wrote g9_variants.json: {os.path.getsize(path) / 1024:.1f} KiB, {len(res['reference_tree']['variants'])} reference variants")
+
+
+# ---------------------------------------------------------------- G10: the seven non-SSIM validation metrics
+def g10():
+    import types
+
+    import fixture_inputs as fi
+    if "torchmetrics" not in sys.modules:
+        tm, tf_, ti = types.ModuleType("torchmetrics"), types.ModuleType("torchmetrics.functional"), types.ModuleType("torchmetrics.functional.image")
+
+        def _absent(*a, **k):
+            raise RuntimeError("torchmetrics is not installed: SSIM stays unpinned")
+        ti.structural_similarity_index_measure = _absent
+        tm.functional, tf_.image = tf_, ti
+        sys.modules.update({"torchmetrics": tm, "torchmetrics.functional": tf_, "torchmetrics.functional.image": ti})
+    from training import metrics as ref_m                # reference
+    pred, tgt, em, co = (torch.from_numpy(a) for a in fi.metrics_inputs())
+    arrs = {}
+    for k, v in ref_m.compute_per_channel_mse(pred, tgt).items():
+        arrs[k] = np.float64(v)
+    for pm in ("zeros", "replicate", "reflect", "circular"):
+        for st in ("forward", "central"):
+            arrs[f"gradient_l1/{pm}/{st}"] = np.float64(ref_m.compute_gradient_l1(pred[:, 0], tgt[:, 0], 0.0625, 0.0625, pm, st))
+            arrs[f"divergence_norm/{pm}/{st}"] = np.float64(ref_m.compute_divergence_norm(pred[:, 1], pred[:, 2], 0.0625, 0.0625, pm, st))
+    arrs["kinetic_energy"] = np.float64(ref_m.compute_kinetic_energy(pred[:, 1], pred[:, 2]))
+    arrs["collider_violation"] = np.float64(ref_m.compute_collider_violation(pred[:, 0], co))
+    arrs["collider_violation_none"] = np.float64(ref_m.compute_collider_violation(pred[2:, 0], co[2:]))
+    arrs["emitter_density_accuracy"] = np.float64(ref_m.compute_emitter_density_accuracy(pred[:, 0], em, 0.8))
+    arrs["emitter_density_accuracy_none"] = np.float64(ref_m.compute_emitter_density_accuracy(pred[:, 0], torch.zeros_like(em), 0.8))
+    tr = ref_m.MetricsTracker()
+    tr.update({"a": 1.0, "b": 2.0})
+    tr.update({"a": 3.0})
+    for k, v in tr.compute_averages().items():
+        arrs[f"tracker/{k}"] = np.float64(v)
+    save("g10_metrics.npz", **arrs)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g7", "g8"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
     for w in which:
         globals()[w]()

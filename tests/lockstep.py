@@ -16,7 +16,7 @@ OUT_SLOTS = {
     "PAD_RING": [0], "HEAD_FWD": [3, 4], "LOSS_REDUCE": [5], "LOSS_FINALIZE": [2, 3], "LOSS_GRAD": [9], "HEAD_BWD": [5, 6, 7],
     "INACT_BWD_REDUCE": [6, 7, 8, 9], "INACT_BWD_APPLY": [6], "AFFINE_GRAD": [1, 2], "AFFINE_GRAD_MULTI": [1], "FOLD_SUM": [2], "POOL2X": [1], "POOL2X_BWD": [2], "DEPTH2SPACE": [2], "SPACE2DEPTH": [1], "NORM_COMBINE": [0, 1, 2], "NORM_COMBINE_BWD": [2], "BIAS_GRAD": [1],
     "ZERO_INSERT": [1], "UPSAMPLE2X_BWD": [1], "UNPACK_GRAD": [1], "ZERO": [0], "PREP_WEIGHTS": [1, 2], "GRAD_NORM": [1],
-    "ADAM": [0, 2, 3], "COPY_PLANES": [1], "UNPREP_WGRAD": [1], "STENCIL": [2, 3], "NOP": [],
+    "ADAM": [0, 2, 3], "COPY_PLANES": [1], "UNPREP_WGRAD": [1], "STENCIL": [2, 3], "NOP": [], "EVENT_RECORD": [], "EVENT_WAIT": [],
 }
 
 

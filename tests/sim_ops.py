@@ -126,6 +126,13 @@ class Sim:
     def op_NOP(self, r):
         pass
 
+    # lanes (fluidnet_hip.h): the twin executes the records in plan order on one thread, which is one of the orders the events allow
+    def op_EVENT_RECORD(self, r):
+        pass
+
+    def op_EVENT_WAIT(self, r):
+        pass
+
     def op_PACK_INPUT(self, r):
         B, H, W, Cpad, pm = r.i[:5]
         st = r.i[5:11]

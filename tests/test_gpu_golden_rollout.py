@@ -1,0 +1,147 @@
+"""The reference-generated fixtures G3 (K = 4 rollout loss, all three modes), G7 (clip + Adam, three steps) and G8 (16-frame
+autoregressive rollout) against the HIP path on the GPU -- through the native plans (RolloutTrainPlan / RolloutInferPlan), i.e.
+fnet_plan_run / fnet_graph_launch of the C ABI, not through torch autograd.
+
+Reference behaviour pinned here: ml/training/trainer.py:311-385 (weighted-average mode, rollout_gradient_truncation,
+rollout_final_step_only), trainer.py:164-195 (clip_grad_norm_ + Adam), ml/scripts/simple_infer.py:226-260.
+Tolerances: fp32 plan -- loss 1e-5 rel, last prediction max-abs 2e-3 (K = 4 chained applications; one frame of G8: 2e-4), per-tensor gradients rel-L2 5e-4 (+1e-6 abs floor), parameters
+after Adam as in tests/test_oracle_golden.py::test_g7_adam_clip; bf16 plan (G8 only) -- the bf16 bar of tests/test_gpu_api.py.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import fluidnet_oracle as orc
+from fluidnet_amd.engine.rollout_plan import RolloutInferPlan
+from fluidnet_amd.engine.train_plan import RolloutTrainPlan
+from fluidnet_amd.models.unet import UNet, UNetConfig
+from fluidnet_amd.training.dp import dp_train_step
+from fluidnet_amd.training.physics_loss import PhysicsAwareLoss
+from helpers import loss_c2, relerr, tiny_cfg, unpack
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _crit(lc):
+    return PhysicsAwareLoss(lc.mse_weight, lc.divergence_weight, lc.gradient_weight, lc.emitter_weight, lc.grid_spacing,
+                            lc.enable_divergence, lc.enable_gradient, lc.enable_emitter, lc.padding_mode, lc.stencil_mode)
+
+
+def _model(cfg, seed, precision="fp32"):
+    m = UNet(UNetConfig(**cfg.__dict__), precision=precision)
+    m.load_state_dict(orc.make_params(cfg, seed=seed))
+    return m.to(DEV)
+
+
+def _fill(plan, x0, y, mk):
+    plan.x0.tensor.copy_(torch.as_tensor(x0))
+    plan.y.tensor.copy_(torch.as_tensor(y))
+    plan.masks.tensor.copy_(torch.as_tensor(mk))
+
+
+@pytest.mark.parametrize("tag,trunc,fin", [("full", False, False), ("trunc", True, False), ("final", False, True)])
+def test_g3_rollout_k4_native_plan_fp32(golden_dir, tag, trunc, fin):
+    g = np.load(os.path.join(golden_dir, "g3_tiny_rollout_k4.npz"))
+    cfg = tiny_cfg()
+    m = _model(cfg, 13)
+    x0, y, _ = orc.synth_batch(2, 4, 32, seed=303)
+    plan = RolloutTrainPlan(m.cfg, _crit(loss_c2(32)), 2, 32, 32, 4, dtype="fp32", weight_decay=1.10, gradient_truncation=trunc,
+                            final_step_only=fin, clip_norm=None)
+    plan.bind(torch.device(DEV), m.flat_params, m.flat_grads)
+    _fill(plan, x0, y, g["masks"])
+    plan.run(("fwd", "fin", "bwd"))
+    d = plan.loss_dict()
+    for k in ("mse", "divergence", "gradient", "emitter", "total"):
+        ref = float(g[f"{tag}/loss_{k}"])
+        assert abs(d[k] - ref) < 1e-5 * max(1.0, abs(ref)), (tag, k, d[k], ref)
+    pred = plan.tapes[-1].pred.tensor.cpu().numpy()
+    # four chained applications of the random-init tiny net amplify fp32 rounding (tests/test_gpu_api.py allows 2e-3 at K = 2)
+    assert np.abs(pred - g[f"{tag}/pred"]).max() < 2e-3, tag
+    worst = 0.0
+    for k in plan.pb.shapes:
+        got = unpack(plan.pb, m.flat_grads, k)
+        e = relerr(got, g[f"{tag}/grad/{k}"])
+        worst = max(worst, e)
+        assert e < 5e-4, (tag, k, e)
+    print(f"[G3 {tag}] native fp32 plan: total {d['total']:.6f} vs {float(g[f'{tag}/loss_total']):.6f}; worst per-tensor gradient rel-L2 {worst:.2e}")
+
+
+def test_g7_adam_clip_native_plan_fp32(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g7_adam_clip.npz"))
+    cfg = tiny_cfg()
+    m = _model(cfg, 19)
+    plan = RolloutTrainPlan(m.cfg, _crit(loss_c2(32)), 2, 32, 32, 2, dtype="fp32", weight_decay=1.10, clip_norm=0.05)
+    plan.bind(torch.device(DEV), m.flat_params, m.flat_grads)
+    for step in range(1, 4):
+        x0, y, mk = orc.synth_batch(2, 2, 32, seed=700 + step)
+        _fill(plan, x0, y, mk)
+        plan.set_adam_scalars(3e-3, step)
+        dp_train_step(plan, 1)
+        loss = plan.loss_dict()["total"]
+        ref = float(g[f"step{step}/loss"])
+        # step 1 is the fixture's arithmetic exactly; from step 2 on the weights carry the first update's Adam noise (see below: with
+        # lr = 3e-3 an element whose clipped gradient is of the order of eps moves anywhere in [-lr, lr]), which changes the loss in the
+        # 4th digit and the gradient norm by a fraction of a percent
+        assert abs(loss - ref) < (1e-5 if step == 1 else 1e-3) * max(1.0, abs(ref)), (step, loss, ref)
+        norm = float(torch.sqrt(plan.normsq.tensor[0]))
+        assert abs(norm - float(g[f"step{step}/grad_norm"])) < (1e-3 if step == 1 else 2e-2) * norm, (step, norm)
+        if step in (1, 3):
+            for k in plan.pb.shapes:
+                got = unpack(plan.pb, m.flat_params.detach(), k).cpu().numpy()
+                diff = np.abs(got - g[f"step{step}/param/{k}"])
+                # Adam's update is lr * m / (sqrt(v) + eps): for an element whose (clipped) gradient is of the order of eps = 1e-8, or
+                # pure rounding noise (a bias in front of an InstanceNorm: analytically zero), the update is anything in [-lr, lr] and
+                # depends on the summation order of the gradient; everywhere else the fixture is matched closely
+                assert diff.max() <= 3e-3 * step * 1.01, (step, k, float(diff.max()))
+                noise = float(unpack(plan.pb, m.flat_grads, k).norm()) < 1e-6
+                if not noise:
+                    tol = 2e-5 if step == 1 else 3e-4
+                    assert float((diff > tol).mean()) < (0.02 if step == 1 else 0.1), (step, k, float((diff > tol).mean()))
+
+
+@pytest.mark.parametrize("precision,base", [("fp32", 8), ("bf16", 16)])
+def test_g8_rollout16_native_plan(golden_dir, precision, base):
+    """fp32: the tiny net of the fixture, every frame against the reference's frames.  bf16: the MFMA kernels need >= 16 channels,
+    so the same geometry runs on base 16 against the oracle (itself pinned by G8), frame by frame on the GPU's own previous state."""
+    g = np.load(os.path.join(golden_dir, "g8_rollout16.npz"))
+    cfg = tiny_cfg(base_channels=base)
+    params = orc.make_params(cfg, seed=23)
+    m = UNet(UNetConfig(**cfg.__dict__), precision=precision)
+    m.load_state_dict(params)
+    m.to(DEV).eval()
+    em, co = g["emitter"], g["collider"]
+    plan = RolloutInferPlan(m.cfg, 1, 32, 32, params_flat=m.flat_params, dtype=precision)
+    plan.reset(torch.from_numpy(em).to(DEV)[None], torch.from_numpy(co).to(DEV)[None])
+    frames = plan.rollout(16).cpu()
+    assert bool(torch.isfinite(frames).all())
+    if precision == "fp32":
+        # (1) every frame of the fixture from the fixture's own previous frames (teacher forcing): pins each step to the reference
+        gf = torch.from_numpy(g["frames"]).to(DEV)
+        worst = 0.0
+        for f in range(16):
+            st = gf[f - 1][None] if f >= 1 else None
+            pv = gf[f - 2][None, 0] if f >= 2 else None
+            plan.reset(torch.from_numpy(em).to(DEV)[None], torch.from_numpy(co).to(DEV)[None], state=st, prev_density=pv)
+            worst = max(worst, float((plan.step(1)[0] - gf[f]).abs().max()))
+        # (2) the free-running rollout: the random-init net amplifies rounding differences from frame to frame, so only the
+        # first frames can agree with another fp32 implementation; the growth is reported
+        errs = (frames[:, 0] - torch.from_numpy(g["frames"])).abs().amax(dim=(1, 2, 3))
+        print(f"[G8] native fp32 rollout: one step from the reference's own frames, worst of 16: max-abs {worst:.2e}; free-running "
+              f"max-abs per frame {['%.1e' % float(e) for e in errs]}")
+        assert worst < 2e-4
+        assert float(errs[:2].max()) < 2e-4
+        return
+    e, c = torch.from_numpy(em)[None, None], torch.from_numpy(co)[None, None]
+    cur, prev = torch.zeros(1, 3, 32, 32), torch.zeros(1, 1, 32, 32)
+    worst = 0.0
+    with torch.no_grad():
+        for f in range(16):
+            ref = orc.unet_forward(params, cfg, torch.cat([cur, prev, e, c], 1), training=False)
+            rel = float((frames[f] - ref).norm() / (ref.norm() + 1e-12))
+            worst = max(worst, rel)
+            prev, cur = cur[:, 0:1], frames[f]
+    print(f"[G8 bf16] hipGraph rollout, 16 frames, each against the oracle on the same state: worst rel-L2 {worst:.3e}")
+    assert worst < 8e-2

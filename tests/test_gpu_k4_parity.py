@@ -1,0 +1,152 @@
+"""K-step BPTT gradient parity of the benchmarked bf16 MFMA plan (BASELINE config 2's arithmetic) against the fp32 HIP plan, which is
+itself pinned to the reference by the G1/G2/G3 fixtures (tests/test_gpu_api.py, tests/test_gpu_golden_rollout.py).
+
+UNet_medium, 128x128, 4 samples, dropout 0, the same weights and inputs through
+    RolloutTrainPlan(dtype="fp32", conv_impl="ref")   -- fp32 storage, FMA convolutions
+    RolloutTrainPlan(dtype="bf16")                    -- bf16 storage, MFMA convolutions, fp32 accumulate / statistics / loss
+for K = 1, 2, 4 (ml/training/trainer.py:348-385), in two regimes:
+  (a) the seeded random initialisation (orc.make_params): 56 % of the outputs sit on the clamp and the untrained net amplifies a
+      perturbation of its input ~5x per application (measured below: prediction rel-L2 0.04 -> 0.22 -> 0.68 -> 1.08), so from
+      the third application on two correct computations are unrelated and so are their K = 4 gradients.  That this is the
+      problem's conditioning and not the bf16 path is shown with the fp32 plan alone: run on weights and inputs rounded ONCE to
+      bf16 (the "floor" run) it decorrelates from the exact fp32 run the same way.  K = 1 must agree; K >= 2 is bounded by the floor;
+  (b) after 200 K1 Adam steps on a fixed batch -- the regime the reference's curriculum actually runs K4 in: K4 warm-starts from
+      trained K3 weights (ml/scripts/train.py:132-138).  This is the stated bf16 tolerance of the training step:
+          loss within 2e-2 rel, final prediction rel-L2 <= 8e-2, whole-gradient cosine >= BAR_COS[K].
+The numbers of the last run are written to gpurun_out/k4_parity.json (per-tensor cosines included).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import fluidnet_oracle as orc
+from fluidnet_amd.data.synthetic import synth_rollout_batch
+from fluidnet_amd.engine.train_plan import RolloutTrainPlan
+from fluidnet_amd.models.unet import UNet, UNetConfig
+from fluidnet_amd.training.dp import dp_train_step
+from fluidnet_amd.training.physics_loss import PhysicsAwareLoss
+from helpers import unpack
+
+pytestmark = pytest.mark.gpu
+B, R = 4, 128
+BAR_COS = {1: 0.98, 2: 0.96, 4: 0.97}          # trained regime; see DESIGN.md section 5 for the measured values
+
+
+def _crit():
+    return PhysicsAwareLoss(1.0, 0.01, 0.001, 0.01, 2.0 / R, True, True, True, "replicate", "forward")
+
+
+def _model(precision, flat=None, round_bf16=False):
+    cfg = orc.medium_config(dropout=0.0)
+    m = UNet(UNetConfig(**cfg.__dict__), precision=precision, conv_impl="ref" if precision == "fp32" else "auto")
+    m.load_state_dict(orc.make_params(cfg, seed=7))
+    m.to("cuda")
+    if flat is not None:
+        m.flat_params.data.copy_(flat)
+    if round_bf16:
+        m.flat_params.data.copy_(m.flat_params.data.bfloat16().float())
+    return m
+
+
+def _run(model, precision, K, batch):
+    p = RolloutTrainPlan(model.cfg, _crit(), B, R, R, K, dtype=precision, conv_impl="ref" if precision == "fp32" else "auto",
+                         weight_decay=1.10, clip_norm=1.0)
+    p.bind(torch.device("cuda"), model.flat_params, model.flat_grads)
+    x0, y, mk = batch
+    p.x0.tensor.copy_(torch.from_numpy(x0))
+    p.y.tensor.copy_(torch.from_numpy(np.ascontiguousarray(y[:, :K])))
+    p.masks.tensor.copy_(torch.from_numpy(np.ascontiguousarray(mk[:, :K])))
+    p.run(("fwd", "fin", "bwd"))
+    torch.cuda.synchronize()
+    out = dict(loss=p.loss_dict()["total"], preds=[t.pred.tensor.clone() for t in p.tapes], grads=model.flat_grads.detach().double().clone(),
+               pb=p.pb)
+    del p
+    return out
+
+
+def _compare(a32, a16, K):
+    g32, g16 = a32["grads"], a16["grads"]
+    cos = float(torch.dot(g32, g16) / (g32.norm() * g16.norm()))
+    rel = float((g16 - g32).norm() / g32.norm())
+    per = {}
+    for k in a32["pb"].shapes:
+        t32, t16 = unpack(a32["pb"], g32, k).flatten(), unpack(a16["pb"], g16, k).flatten()
+        if float(t32.norm()) > 1e-3 * float(g32.norm()):
+            per[k] = float(torch.dot(t32, t16) / (t32.norm() * t16.norm() + 1e-300))
+    prel = [float((q - p).norm() / p.norm()) for p, q in zip(a32["preds"], a16["preds"])]
+    return dict(K=K, loss32=a32["loss"], loss16=a16["loss"], grad_cos=cos, grad_rel=rel, gnorm32=float(g32.norm()), gnorm16=float(g16.norm()),
+                pred_rel=prel, worst_tensor=min(per.items(), key=lambda kv: kv[1]), per_tensor_cos=per)
+
+
+@pytest.fixture(scope="module")
+def batch():
+    return synth_rollout_batch(B, 4, R, seed=4321)
+
+
+@pytest.fixture(scope="module")
+def trained(batch):
+    """200 K1 Adam steps (lr 1e-3, clip 1.0) of the bf16 plan on the fixed batch, from the seeded initialisation."""
+    m = _model("bf16")
+    p = RolloutTrainPlan(m.cfg, _crit(), B, R, R, 1, dtype="bf16", weight_decay=1.10, clip_norm=1.0)
+    p.bind(torch.device("cuda"), m.flat_params, m.flat_grads)
+    x0, y, mk = batch
+    p.x0.tensor.copy_(torch.from_numpy(x0))
+    p.y.tensor.copy_(torch.from_numpy(np.ascontiguousarray(y[:, :1])))
+    p.masks.tensor.copy_(torch.from_numpy(np.ascontiguousarray(mk[:, :1])))
+    first = None
+    for step in range(1, 201):
+        p.set_adam_scalars(1e-3, step)
+        dp_train_step(p, 1)
+        if step == 1:
+            first = p.loss_dict()["total"]
+    last = p.loss_dict()["total"]
+    print(f"[k4 parity] warm-up training: K1 loss {first:.5f} -> {last:.5f} after 200 steps")
+    assert np.isfinite(last) and last < 0.5 * first
+    return m.flat_params.detach().clone()
+
+
+_REPORT = {}
+
+
+def _dump():
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(os.path.join("gpurun_out", "k4_parity.json"), "w") as f:
+        json.dump(_REPORT, f, indent=1)
+
+
+def _rounded(batch):
+    x0, y, mk = batch
+    return torch.from_numpy(x0).bfloat16().float().numpy(), y, mk
+
+
+@pytest.mark.parametrize("K", [1, 2, 4])
+def test_bf16_vs_fp32_plan_at_random_init(batch, K):
+    exact = _run(_model("fp32"), "fp32", K, batch)
+    r = _compare(exact, _run(_model("bf16"), "bf16", K, batch), K)
+    fl = _compare(exact, _run(_model("fp32", round_bf16=True), "fp32", K, _rounded(batch)), K)
+    r["floor_grad_cos"], r["floor_pred_rel"] = fl["grad_cos"], fl["pred_rel"]
+    _REPORT[f"init/K{K}"] = r
+    _dump()
+    print(f"[k4 parity] init K={K}: conditioning floor (fp32 plan on weights/inputs rounded once to bf16 vs exact fp32 plan): pred rel-L2 "
+          f"{['%.3f' % v for v in fl['pred_rel']]}, gradient cos {fl['grad_cos']:.4f}")
+    print(f"[k4 parity] init K={K}: loss {r['loss16']:.5f} vs {r['loss32']:.5f}; pred rel-L2 per application {['%.3f' % v for v in r['pred_rel']]}; "
+          f"gradient cos {r['grad_cos']:.4f} rel-L2 {r['grad_rel']:.3f} norms {r['gnorm16']:.2f}/{r['gnorm32']:.2f}; worst tensor {r['worst_tensor']}")
+    assert abs(r["loss16"] - r["loss32"]) < 3e-2 * abs(r["loss32"])
+    assert r["pred_rel"][0] < 8e-2
+    # one application must agree; beyond it the bar is the floor run's own agreement with the exact run (module docstring)
+    assert r["grad_cos"] > (0.93 if K == 1 else min(0.93, fl["grad_cos"]) - 0.15) and 0.5 < r["gnorm16"] / r["gnorm32"] < 2.0
+
+
+@pytest.mark.parametrize("K", [1, 2, 4])
+def test_bf16_vs_fp32_plan_after_training(batch, trained, K):
+    r = _compare(_run(_model("fp32", trained), "fp32", K, batch), _run(_model("bf16", trained), "bf16", K, batch), K)
+    _REPORT[f"trained/K{K}"] = r
+    _dump()
+    print(f"[k4 parity] trained K={K}: loss {r['loss16']:.5f} vs {r['loss32']:.5f}; pred rel-L2 per application {['%.3f' % v for v in r['pred_rel']]}; "
+          f"gradient cos {r['grad_cos']:.4f} rel-L2 {r['grad_rel']:.3f} norms {r['gnorm16']:.2f}/{r['gnorm32']:.2f}; worst tensor {r['worst_tensor']}")
+    assert abs(r["loss16"] - r["loss32"]) < 2e-2 * abs(r["loss32"])
+    assert r["pred_rel"][-1] < 8e-2
+    assert r["grad_cos"] > BAR_COS[K], r["grad_cos"]

@@ -52,3 +52,27 @@ def test_reference_named_functions_and_strided_views():
     tr = M.MetricsTracker()
     tr.update({"a": 1.0}); tr.update({"a": 3.0, "b": 2.0})
     assert tr.compute_averages() == {"a": 2.0, "b": 2.0}
+
+
+def test_g10_reference_metrics_fixture(golden_dir):
+    """The HIP METRICS kernel (through the reference-named functions) against the values the REAL ml/training/metrics.py produced for
+    tests/fixture_inputs.py::metrics_inputs (tests/golden/make_golden.py g10); SSIM is not in the fixture (torchmetrics absent)."""
+    import os
+
+    import fixture_inputs as fi
+    g = np.load(os.path.join(golden_dir, "g10_metrics.npz"))
+    pred, tgt, em, co = (torch.from_numpy(a).cuda() for a in fi.metrics_inputs())
+    for k, v in M.compute_per_channel_mse(pred, tgt).items():
+        assert abs(v - float(g[k])) < 1e-6 * max(1.0, abs(float(g[k]))), k
+    for pm in ("zeros", "replicate", "reflect", "circular"):
+        for st in ("forward", "central"):
+            ref = float(g[f"gradient_l1/{pm}/{st}"])
+            assert abs(M.compute_gradient_l1(pred[:, 0], tgt[:, 0], 0.0625, 0.0625, pm, st) - ref) < 1e-5 * max(1.0, abs(ref)), (pm, st)
+            ref = float(g[f"divergence_norm/{pm}/{st}"])
+            assert abs(M.compute_divergence_norm(pred[:, 1], pred[:, 2], 0.0625, 0.0625, pm, st) - ref) < 1e-5 * max(1.0, abs(ref)), (pm, st)
+    ref = float(g["kinetic_energy"])
+    assert abs(M.compute_kinetic_energy(pred[:, 1], pred[:, 2]) - ref) < 1e-5 * ref
+    assert abs(M.compute_collider_violation(pred[:, 0], co) - float(g["collider_violation"])) < 1e-6
+    assert M.compute_collider_violation(pred[2:, 0], co[2:]) == 0.0
+    assert abs(M.compute_emitter_density_accuracy(pred[:, 0], em, 0.8) - float(g["emitter_density_accuracy"])) < 1e-6
+    assert M.compute_emitter_density_accuracy(pred[:, 0], torch.zeros_like(em), 0.8) == 0.0

@@ -90,3 +90,37 @@ def test_gather_matches_dataset_getitem(npz_root, K, normalize, preload):
     # DataLoader-style iteration yields the dataset's tuple shapes
     b = next(iter(ld))
     assert len(b) == (2 if K == 1 else 3) and b[0].shape == (4, 6, 12, 20)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,preload", [(1, True), (4, True), (4, False)])
+def test_gather_matches_reference_fixture_g6(golden_dir, tmp_path, K, preload):
+    """GATHER_BATCH against what the REAL ml/dataset/npz_sequence.py returned for the same files (tests/golden/make_golden.py g6):
+    both mask conventions, bit for bit, and the flipped tuples of ml/dataset/augmentations.py."""
+    import os
+
+    import fixture_inputs as fi
+    g = np.load(os.path.join(golden_dir, "g6_dataset.npz"))
+    root = fi.write_synth_npz(tmp_path)
+    ds = FluidNPZSequenceDataset(root, "train", rollout_steps=K, preload=preload, stride=1)
+    Km = K if (preload or K == 1) else K + 1
+    ld = HbmBatchLoader(HbmSequenceStore(ds), 3, shuffle=False, mask_frames=Km)
+    pre = f"K{K}/pre{int(preload)}/s1"
+    rows = np.array([0, len(ds) // 2, len(ds) - 1])
+    x0 = torch.empty(3, 6, 16, 20, device="cuda")
+    y = torch.empty(3, K, 3, 16, 20, device="cuda")
+    mk = torch.empty(3, Km, 2, 16, 20, device="cuda")
+    ld.gather(rows, np.zeros(3, np.int32), x0, y, mk)
+    for j, idx in enumerate(rows):
+        assert np.array_equal(x0[j].cpu().numpy(), g[f"{pre}/item{idx}/0"])
+        if K == 1:
+            assert np.array_equal(y[j, 0].cpu().numpy(), g[f"{pre}/item{idx}/1"])
+            # single-step batches: the model input and the loss masks are those of frame t (npz_sequence.py:144-153, trainer.py:187-188)
+            assert np.array_equal(mk[j, 0].cpu().numpy(), g[f"{pre}/item{idx}/0"][4:6])
+        else:
+            assert np.array_equal(y[j].cpu().numpy(), g[f"{pre}/item{idx}/1"])
+            assert np.array_equal(mk[j].cpu().numpy(), g[f"{pre}/item{idx}/2"])
+    if K == 4 and not preload:          # the flipped rollout tuple of the fixture is item 2 of this very dataset
+        ld.gather(np.array([2, 2, 2]), np.ones(3, np.int32), x0, y, mk)
+        for j, t in enumerate((x0, y, mk)):
+            assert np.array_equal(t[0].cpu().numpy(), g[f"flip_on/rollout/{j}"])

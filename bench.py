@@ -29,6 +29,7 @@ from fluidnet_amd.engine.train_plan import RolloutTrainPlan  # noqa: E402
 from fluidnet_amd.models.unet import UNet, UNetConfig  # noqa: E402
 from fluidnet_amd.training.dp import dp_train_step, torch_all_reduce  # noqa: E402
 from fluidnet_amd.training.physics_loss import PhysicsAwareLoss  # noqa: E402
+from fluidnet_amd.training.trainer import step_seed  # noqa: E402
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0      # MI355X dense bf16 (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0
@@ -98,7 +99,7 @@ class TrainStepper:
     def __init__(self, B, R, K, precision, world, rank, lr=3e-4, conv_impl="auto", arch="medium", depth=None):
         torch.manual_seed(42)
         self.model = UNet(arch_cfg(arch, depth=depth), precision=precision, conv_impl=conv_impl).cuda()
-        self.world = world
+        self.world, self.rank = world, rank
         self.lr = lr
         self.plan = RolloutTrainPlan(self.model.cfg, c2_loss(R), B, R, R, K, dtype=precision, conv_impl=conv_impl, world=world,
                                      weight_decay=1.10, clip_norm=1.0, seed=1234 + rank)
@@ -123,7 +124,7 @@ class TrainStepper:
         self.t += 1
         p = self.plan
         p.set_adam_scalars(self.lr, self.t)
-        p.set_dropout_seed(self.t * 7919 + 13)
+        p.set_dropout_seed(step_seed(self.t, self.rank))
         dp_train_step(p, self.world, torch_all_reduce(self.dist) if self.world > 1 else None)
 
 

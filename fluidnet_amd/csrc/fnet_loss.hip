@@ -580,6 +580,7 @@ int fnet_op_metrics(const FnetOp& op, hipStream_t st) {
     FNET_CHECK_ARG(op.p[0] && op.p[1] && op.p[2] && op.p[3] && op.p[4]);
     FNET_CHECK_ARG(op.i[3] >= 3 * H * W && op.i[4] >= H * W && op.i[5] >= H * W);
     FNET_CHECK_ARG(op.i[6] >= 0 && op.i[6] <= 3 && op.i[7] >= 0 && op.i[7] <= 1 && op.f[0] > 0.f);
+    FNET_CHECK_ARG(!(op.i[8] & 1) || (H > 10 && W > 10));   // SSIM: the library's crop leaves nothing otherwise (checked before any launch)
     MetricArgs a;
     a.pred = (const float*)op.p[0];
     a.tgt = {(const float*)op.p[1], op.i[3]};
@@ -590,7 +591,6 @@ int fnet_op_metrics(const FnetOp& op, hipStream_t st) {
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(k_metrics_reduce, dim3(blocks), dim3(kThreads), 0, st, a, (double*)op.p[4]);
     if (op.i[8] & 1) {
-        FNET_CHECK_ARG(H > 10 && W > 10);            // the library's crop leaves nothing otherwise
         int sb = (B * (H - 10) * (W - 10) + kThreads - 1) / kThreads;
         if (sb > 4096) sb = 4096;
         hipLaunchKernelGGL(k_ssim_density, dim3(sb), dim3(kThreads), 0, st, a.pred, a.tgt, B, H, W, (double*)op.p[4]);

@@ -166,6 +166,15 @@ int fnet_plan_run(const FnetOp* ops, int32_t n_ops, void* stream, int32_t* faile
     return FNET_OK;
 }
 
+int fnet_lane_stream(int32_t lane, void** stream_out) {
+    if (!stream_out || lane < 1 || lane >= FNET_MAX_LANES) return FNET_E_BADARG;
+    hipStream_t st = nullptr;
+    const int rc = lane_stream(lane, nullptr, &st);
+    if (rc != FNET_OK) return rc;
+    *stream_out = (void*)st;
+    return FNET_OK;
+}
+
 int fnet_graph_create(const FnetOp* ops, int32_t n_ops, void** graph_out) {
     if (!ops || n_ops <= 0 || !graph_out) return FNET_E_BADARG;
     hipStream_t cap;

@@ -389,7 +389,9 @@ int fnet_rollout_add_impulse(void* handle, const float* host_impulse_xy, void* s
     hipStream_t st = (hipStream_t)stream;
     if (hipMemcpyAsync(r->impulse, host_impulse_xy, (size_t)n * 4, hipMemcpyHostToDevice, st) != hipSuccess) return FNET_E_HIP;
     hipLaunchKernelGGL(k_add_impulse, dim3((n + 255) / 256), dim3(256), 0, st, r->cur, r->impulse, r->B, HW);
-    return hipGetLastError() == hipSuccess ? FNET_OK : FNET_E_HIP;
+    if (hipGetLastError() != hipSuccess) return FNET_E_HIP;
+    // the host array may be pageable and may go away as soon as this returns (the viewer's input thread): wait for the upload
+    return hipStreamSynchronize(st) == hipSuccess ? FNET_OK : FNET_E_HIP;
 }
 
 int fnet_rollout_step(void* handle, int32_t frames, void* stream) {

@@ -70,6 +70,7 @@ class HbmBatchLoader:
                  rank: int = 0, world: int = 1, mask_frames: Optional[int] = None) -> None:
         self.store, self.B, self.shuffle, self.drop_last = store, batch_size, shuffle, drop_last
         self.seed, self.rank, self.world = seed, rank, world
+        self.sharded = True          # Trainer: rows are already rank-disjoint, do not split the batch again
         ds = store.dataset
         self.K = max(1, ds.rollout_steps)
         self.Km = mask_frames if mask_frames is not None else self.K

@@ -745,11 +745,15 @@ class PlanBuilder:
                 iv += [S.off, C, gw.off if gw is not None else -1, gb.off]
             self.op(ops, "AFFINE_GRAD_MULTI", iv, p=[Ref(self.s_slab), Ref(self.grads)], tag="+".join(g[4] for g in grp))
 
-    def emit_backward(self, ops, t: Tape, dpred: Buf, dx_out: Optional[Buf] = None, dx_channels: int = 6) -> None:
+    def emit_backward(self, ops, t: Tape, dpred: Buf, dx_out: Optional[Buf] = None, dx_channels: int = 6, bucket_cb=None) -> None:
         """Adjoint of emit_forward.  Accumulates parameter gradients (dWk scratch for 3x3 weights, grads_flat for the
-        rest); writes d(input) [B,dx_channels,H,W] fp32 into dx_out when given."""
+        rest); writes d(input) [B,dx_channels,H,W] fp32 into dx_out when given.
+        bucket_cb(ops, prefixes): called when every layer whose name starts with one of `prefixes` has emitted its last gradient
+        op of THIS pass, decoder first (head + ups.*, mid.*, the deepest encoder level); the remaining layers (outer encoder levels,
+        stem) finish with the pass itself.  The data-parallel step starts a bucket's all-reduce there (training/dp.py)."""
         cfg, B, H, W = self.cfg, self.B, self.H, self.W
         zero_at = len(ops)
+        self.op(ops, "NOP", [], tag="S_slab")     # placeholder: becomes the ZERO of this pass's S slab once its size is known
         self.s_slab = None                   # a fresh slab per backward pass: buffers already allocated never change size
         s_begin = 0
         x = t.head_in
@@ -788,8 +792,12 @@ class PlanBuilder:
                         p=[Ref(dcat[L]), Ref(glow)], tag=f"ups.{i}.up")
                 self.release(dcat[L])
             srcs = [GradSrc(PV(glow, C), 0)]
+        if bucket_cb is not None:
+            bucket_cb(ops, ("head.", "ups."))
         for j in reversed(range(len(t.mids))):
             srcs = self._block_bwd(ops, t.mids[j], srcs, True)
+        if bucket_cb is not None and t.mids:
+            bucket_cb(ops, ("mid.",))
         for L in reversed(range(cfg.depth)):
             d = t.downs[L]
             C = d["C"]
@@ -806,6 +814,8 @@ class PlanBuilder:
             if d["res"] is not None:
                 srcs = self._block_bwd(ops, d["res"], srcs, True)
             srcs = self._block_bwd(ops, d["block"], srcs, False)
+            if bucket_cb is not None and L == cfg.depth - 1 and cfg.depth >= 2:
+                bucket_cb(ops, (f"downs.{L}.",))
         need_dx = dx_out is not None
         g = self._plain_conv_bwd(ops, t.stem, srcs, need_dx)
         if need_dx:
@@ -815,8 +825,7 @@ class PlanBuilder:
         self.emit_side_join(ops)
         if self.s_slab is not None and self.s_slab.shape[0] > s_begin:
             nbytes = (self.s_slab.shape[0] - s_begin) * 4
-            z = OpRec(OPC["ZERO"], [nbytes & 0x7FFFFFFF, nbytes >> 31], [], [Ref(self.s_slab, s_begin)], self.dtype, "S_slab")
-            ops.insert(zero_at, z)
+            ops[zero_at] = OpRec(OPC["ZERO"], [nbytes & 0x7FFFFFFF, nbytes >> 31], [], [Ref(self.s_slab, s_begin)], self.dtype, "S_slab")
 
     # -------------------------------------------------------------------------------------------- weights / optimiser
     def emit_prep_weights(self, ops) -> None:
@@ -835,10 +844,26 @@ class PlanBuilder:
         self.emit_zero(ops, self.grads)
         self.emit_zero(ops, self.dwk_slab)
 
-    def emit_unprep(self, ops) -> None:
+    def emit_unprep(self, ops, prefixes=None, skip=(), lane: int = 0) -> List[str]:
+        """dWk (tap-major accumulators) -> OIHW gradients in grads_flat, for the convolutions whose name starts with one of `prefixes`
+        (default: all) and is not in `skip`; returns the names emitted."""
+        done = []
         for name, c in self.convs.items():
+            if name in skip or (prefixes is not None and not name.startswith(tuple(prefixes))):
+                continue
             self.op(ops, "UNPREP_WGRAD", [c["Cout"], c["Cin"], c["Cin_pad"], 0, c["Cout_pad"], c.get("tr", 0)],
-                    p=[Ref(c["dWk"]), self.gref(name + ".weight")], tag=name)
+                    p=[Ref(c["dWk"]), self.gref(name + ".weight")], tag=name, lane=lane)
+            done.append(name)
+        return done
+
+    def param_range(self, prefixes) -> Tuple[int, int]:
+        """[lo, hi) in floats of the flat parameter / gradient buffer covered by the tensors whose name starts with one of `prefixes`
+        (they are contiguous: state-dict order is stem, downs.*, mid.*, ups.*, head)."""
+        names = list(self.offsets)
+        idx = [i for i, k in enumerate(names) if k.startswith(tuple(prefixes))]
+        assert idx and idx == list(range(idx[0], idx[-1] + 1)), prefixes
+        hi = self.offsets[names[idx[-1] + 1]] if idx[-1] + 1 < len(names) else self.n_params_padded
+        return self.offsets[names[idx[0]]], hi
 
     # -------------------------------------------------------------------------------------------- loss
     def loss_ops_args(self, lc, tgt: Tuple[Ref, int], in0: Tuple[Ref, int], emit: Tuple[Ref, int], coll: Tuple[Ref, int]):

@@ -49,6 +49,7 @@ def lib() -> ctypes.CDLL:
             f"{LIB_PATH} not found: the HIP extension is not built. Run `python -m fluidnet_amd.build` "
             "(hipcc, gfx950). fluidnet_amd has no CPU fallback.")
     L = ctypes.CDLL(LIB_PATH)
+    fp = ctypes.c_void_p
     L.fnet_abi_version.restype = ctypes.c_int
     L.fnet_strerror.restype = ctypes.c_char_p
     L.fnet_strerror.argtypes = [ctypes.c_int]
@@ -62,7 +63,8 @@ def lib() -> ctypes.CDLL:
     L.fnet_graph_launch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32]
     L.fnet_graph_destroy.restype = ctypes.c_int
     L.fnet_graph_destroy.argtypes = [ctypes.c_void_p]
-    fp = ctypes.c_void_p
+    L.fnet_lane_stream.restype = ctypes.c_int
+    L.fnet_lane_stream.argtypes = [ctypes.c_int32, ctypes.POINTER(ctypes.c_void_p)]
     L.fnet_spatial_gradients.restype = ctypes.c_int
     L.fnet_spatial_gradients.argtypes = [fp, fp, fp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_float,
                                          ctypes.c_float, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]
@@ -95,7 +97,7 @@ def lib() -> ctypes.CDLL:
     return L
 
 
-EXPORTS = ["fnet_abi_version", "fnet_strerror", "fnet_last_hip_error", "fnet_device_info", "fnet_plan_run", "fnet_graph_create",
+EXPORTS = ["fnet_abi_version", "fnet_strerror", "fnet_last_hip_error", "fnet_device_info", "fnet_plan_run", "fnet_lane_stream", "fnet_graph_create",
            "fnet_graph_launch", "fnet_graph_destroy", "fnet_spatial_gradients", "fnet_divergence", "fnet_timer_create",
            "fnet_timer_start", "fnet_timer_stop", "fnet_timer_elapsed_ms", "fnet_timer_destroy", "fnet_unet_param_count",
            "fnet_rollout_create", "fnet_rollout_set_weights", "fnet_rollout_set_masks", "fnet_rollout_set_state", "fnet_rollout_add_impulse",
@@ -128,6 +130,13 @@ def run_ops(ops: np.ndarray, stream: Optional[int] = None) -> None:
     failed = ctypes.c_int32(-1)
     rc = lib().fnet_plan_run(ops.ctypes.data_as(ctypes.c_void_p), len(ops), ctypes.c_void_p(st), ctypes.byref(failed))
     check(rc, "fnet_plan_run", ops, failed.value)
+
+
+def lane_stream(lane: int) -> int:
+    """hipStream_t of side lane `lane` (1 .. FNET_MAX_LANES-1) on the current device, created on first use."""
+    h = ctypes.c_void_p()
+    check(lib().fnet_lane_stream(lane, ctypes.byref(h)), "fnet_lane_stream")
+    return int(h.value)
 
 
 class Graph:

@@ -23,6 +23,7 @@ class RolloutTrainPlan:
                  clip_norm: Optional[float] = 1.0, betas=(0.9, 0.999), eps: float = 1e-8):
         self.cfg, self.lc, self.B, self.H, self.W, self.K = cfg, lc, B, H, W, K
         self.world = world
+        self.mask_offset = mask_offset
         if world > 1 and cfg.norm == "batch":
             raise NotImplementedError("BatchNorm2d under data parallelism would normalise with per-rank batch statistics (the reference "
                                       "has no multi-GPU path to mirror); shard UNet_small runs by experiment, not by batch")
@@ -85,6 +86,28 @@ class RolloutTrainPlan:
         pb.emit_zero_grads(s_bwd)
         dnext = None
         self.dpred = pb.new_buf("dpred", (B, 3, H, W), "f32")
+        # Gradient buckets (data parallel): parameter gradients accumulate over all K applications and are final when the LAST
+        # backward pass emitted (k = 0 unless truncated) has visited their layer.  That pass reports, decoder first, when a group of
+        # layers is complete; the group's 3x3 weight gradients are folded to OIHW right there (on the weight-gradient lane, behind the
+        # launches they depend on) and `grad_buckets` records (index into the bwd section, [lo, hi) of the flat gradient buffer), so
+        # that training/dp.py can start that range's all-reduce while the rest of the pass still runs.
+        self.grad_buckets: List[tuple] = []
+        unprepped: List[str] = []
+
+        def bucket_ready(ops, prefixes):
+            pb.flush_affine(ops)
+            lane = pb.wgrad_lane
+            if lane:
+                pb.emit_lane_edge(ops, 0, lane)      # gamma / beta / bias gradients of the group were written on lane 0
+            unprepped.extend(pb.emit_unprep(ops, prefixes, lane=lane))
+            self.grad_buckets.append((len(ops), pb.param_range(prefixes), lane))
+
+        passes, flows = [], False             # the applications that get a backward pass (same rule as the loop below)
+        for k in reversed(range(K)):
+            if w[k] == 0.0 and not flows:
+                continue
+            passes.append(k)
+            flows = k > 0 and not gradient_truncation
         for k in reversed(range(K)):
             if w[k] == 0.0 and dnext is None:
                 continue
@@ -93,9 +116,18 @@ class RolloutTrainPlan:
                               gcnt=Ref(self.gcnt, k) if world > 1 else None, world=world)
             pass_down = k > 0 and not gradient_truncation
             dx = pb.new_buf(f"dxin{k}", (B, 4, H, W), "f32") if pass_down else None
-            pb.emit_backward(s_bwd, self.tapes[k], self.dpred, dx, 4)
+            last = k == (passes[-1] if passes else 0)
+            pb.emit_backward(s_bwd, self.tapes[k], self.dpred, dx, 4, bucket_cb=bucket_ready if (last and world > 1) else None)
             dnext = (Ref(dx), 4 * HW) if pass_down else None
-        pb.emit_unprep(s_bwd)
+        pb.emit_unprep(s_bwd, skip=unprepped)
+        # the rest of the flat buffer (outer encoder levels, stem; everything when there are no earlier buckets) completes here
+        covered = [r for _, r, _ in self.grad_buckets]
+        lo_rest = 0
+        hi_rest = min([r[0] for r in covered], default=pb.n_params_padded)
+        self.grad_buckets.append((len(s_bwd), (lo_rest, hi_rest), 0))
+        tiles = sorted(r for _, r, _ in self.grad_buckets)
+        assert tiles[0][0] == 0 and tiles[-1][1] == pb.n_params_padded and all(a[1] == b[0] for a, b in zip(tiles, tiles[1:])), \
+            f"gradient buckets must tile the flat buffer: {tiles}"
         # ---------------- section 3: clip + Adam
         s_opt: List[OpRec] = []
         n = pb.n_params_padded

@@ -5,43 +5,78 @@ One process per GPU; rank r owns B samples end to end (InstanceNorm and Dropout2
 stay on one GPU).  Two exchange steps per optimisation step:
   1. all-reduce (SUM) of the K fluid-cell counts -- divergence_loss / gradient_loss normalise by the BATCH-wide count
      (ml/training/physics_loss.py:119-124,153-161), so every shard must use the global denominator for the sum of shard
-     gradients to be the exact global-batch gradient (LOSS_FINALIZE / LOSS_GRAD take `gcnt` and `world`);
-  2. all-reduce (AVG) of the flat fp32 gradient buffer (24.1 MB for UNet_medium).  It is issued once, after backward:
-     gradients of a K-step rollout accumulate over all K applications and are only final when the last one (k = 0) has
-     finished, so there is nothing to overlap earlier; 24 MB over xGMI is ~0.3 ms against a ~45 ms step.
+     gradients to be the exact global-batch gradient (LOSS_FINALIZE / LOSS_GRAD take `gcnt` and `world`).  The counts depend on
+     the masks alone, which are INPUTS: they are counted and exchanged when the batch is loaded, before the forward pass, and
+     the (asynchronous) all-reduce is only waited for when the losses are finalised;
+  2. all-reduce (AVG) of the flat fp32 gradient buffer (24.1 MB for UNet_medium) in BUCKETS, decoder first: gradients of a
+     K-step rollout accumulate over all K applications, so a layer's gradient is final once the last backward pass (k = 0)
+     has visited it; the plan marks those points (RolloutTrainPlan.grad_buckets: head + ups.*, mid.*, the deepest encoder
+     level, the rest) and each bucket's all-reduce is started there, on the stream that produced its last piece, while the
+     remaining layers of the pass are still being computed.  RCCL runs it on its own stream; only clip + Adam wait for it.
 Clip-norm + Adam then run identically on every rank on the averaged gradient.
 """
 from __future__ import annotations
 
-from typing import Callable, Optional
+from typing import Callable, List, Optional
 
 import torch
 
+from ..engine import runtime as rt
 
-def dp_train_step(plan, world: int, all_reduce: Optional[Callable] = None, run: Optional[Callable] = None, avg: bool = True) -> None:
-    """One optimisation step of `plan` (RolloutTrainPlan built with world=world).
 
-    all_reduce(tensor, op) with op in {"sum", "avg"} reduces in place across ranks (torch.distributed in production);
-    run(section_name) executes one plan section (default: plan.run on the current HIP stream)."""
+def fluid_counts(plan) -> torch.Tensor:
+    """fp64 [K]: this shard's fluid-cell count of every rollout step, from the mask planes the plan was loaded with -- the
+    same number LOSS_REDUCE leaves in sums[k][5] (cells with emitter == 0 and collider == 0, physics_loss.py:113-117)."""
+    m = plan.masks.tensor
+    off = plan.mask_offset
+    sel = m[:, off:off + plan.K]
+    return ((sel[:, :, 0] == 0) & (sel[:, :, 1] == 0)).sum(dim=(0, 2, 3)).to(torch.float64)
+
+
+def dp_train_step(plan, world: int, all_reduce: Optional[Callable] = None, run: Optional[Callable] = None, avg: bool = True,
+                  run_slice: Optional[Callable] = None) -> None:
+    """One optimisation step of `plan` (RolloutTrainPlan built with world=world) whose x0 / y / masks are already loaded.
+
+    all_reduce(tensor, op, stream=None) with op in {"sum", "avg"} reduces in place across ranks and returns None or a handle
+    with .wait() (torch.distributed in production: torch_all_reduce); `stream` = the hipStream_t whose queued work the
+    reduction must follow (None: the current stream).
+    run(section_name) executes one plan section (default: plan.run on the current HIP stream); run_slice(name, a, b) executes
+    ops [a, b) of a section (default: the lowered plan; the CPU tests pass the twin's interpreter for both)."""
     run = run or (lambda name: plan.run((name,)))
     if world == 1:
         for name in ("fwd", "fin", "bwd", "opt"):
             run(name)
         return
     assert all_reduce is not None
+    if run_slice is None:
+        run_slice = lambda name, a, b: rt.run_ops(plan._lowered[name][a:b])      # noqa: E731
+    pending: List = []
+    plan.gcnt.tensor.copy_(fluid_counts(plan))
+    pending.append(all_reduce(plan.gcnt.tensor, "sum"))         # overlaps the forward pass
     run("fwd")
-    # sums[k][5] = this shard's fluid-cell count of rollout step k (fp64)
-    plan.gcnt.tensor.copy_(torch.stack([s.tensor[5] for s in plan.sums]))
-    all_reduce(plan.gcnt.tensor, "sum")
+    _wait(pending)
     run("fin")
-    run("bwd")
-    all_reduce(plan.pb.grads.tensor, "avg" if avg else "sum")
+    g = plan.pb.grads.tensor
+    a = 0
+    for end, (lo, hi), lane in plan.grad_buckets:
+        run_slice("bwd", a, end)
+        a = end
+        if hi > lo:
+            pending.append(all_reduce(g[lo:hi], "avg" if avg else "sum", stream=rt.lane_stream(lane) if (lane and g.is_cuda) else None))
+    _wait(pending)
     run("opt")
+
+
+def _wait(pending: List) -> None:
+    for h in pending:
+        if h is not None:
+            h.wait()                     # torch.distributed: the current stream waits for the collective's stream
+    pending.clear()
 
 
 def torch_all_reduce(dist):
     """Adapter from torch.distributed (backend nccl = RCCL on ROCm, or gloo in the CPU tests) to dp_train_step's callback."""
-    def f(t: torch.Tensor, op: str) -> None:
+    def f(t: torch.Tensor, op: str, stream: Optional[int] = None):
         if dist.get_backend() == "gloo":                      # CPU tests / rehearsal: no AVG, and device tensors go through the host
             h = t.detach().cpu() if t.is_cuda else t
             dist.all_reduce(h, op=dist.ReduceOp.SUM)
@@ -49,6 +84,11 @@ def torch_all_reduce(dist):
                 h.div_(dist.get_world_size())
             if t.is_cuda:
                 t.copy_(h)
-        else:
-            dist.all_reduce(t, op=dist.ReduceOp.AVG if op == "avg" else dist.ReduceOp.SUM)
+            return None
+        rop = dist.ReduceOp.AVG if op == "avg" else dist.ReduceOp.SUM
+        if stream is None:
+            return dist.all_reduce(t, op=rop, async_op=True)
+        # RCCL's stream waits for what is queued on the CURRENT stream at call time: make that the lane that produced the bucket
+        with torch.cuda.stream(torch.cuda.ExternalStream(stream)):
+            return dist.all_reduce(t, op=rop, async_op=True)
     return f

@@ -70,6 +70,13 @@ class _Scheduler:
         self.epoch, self.best, self.bad, self.base_lr = s["epoch"], s["best"], s["bad"], s["base_lr"]
 
 
+def step_seed(step: int, rank: int = 0) -> int:
+    """Dropout2d seed of optimisation step `step` on data-parallel rank `rank`: ranks must not share channel masks for their
+    local sample n (the hash mixes seed, layer site, n and c: fnet_common.h drop_scale)."""
+    x = (step * 7919 + 13) ^ ((rank * 0x9E3779B1 + 0x7F4A7C15) & 0x7FFFFFFF if rank else 0)
+    return x & 0x7FFFFFFF
+
+
 class Trainer:
     def __init__(self, model, train_loader, val_loader, config, device: str, *, engine: str = "plan", max_plans: int = 2) -> None:
         if engine not in ("plan", "autograd"):
@@ -105,6 +112,11 @@ class Trainer:
                 self._dist = dist
         except Exception:
             self._dist = None
+        self._rank = self._dist.get_rank() if self._dist is not None else 0
+        self._world = self._dist.get_world_size() if self._dist is not None else 1
+        if self._dist is not None and engine != "plan":
+            # the autograd engine has no gradient exchange: ranks would silently train different models
+            raise NotImplementedError("data-parallel training (torch.distributed initialised with world_size > 1) needs engine='plan'")
 
     # ------------------------------------------------------------------ the K-step rollout loss, literal loop
     def _compute_rollout_loss(self, x_0: torch.Tensor, y_seq: torch.Tensor, masks: torch.Tensor):
@@ -180,8 +192,8 @@ class Trainer:
         """One optimisation step of a plan whose x0 / y / masks buffers are already filled."""
         self.optimizer.step_count += 1
         plan.set_adam_scalars(self.optimizer.param_groups[0]["lr"], self.optimizer.step_count)
-        plan.set_dropout_seed(self.optimizer.step_count * 7919 + 13)
-        world = self._dist.get_world_size() if self._dist is not None else 1
+        plan.set_dropout_seed(step_seed(self.optimizer.step_count, self._rank))
+        world = self._world
         dp_train_step(plan, world, torch_all_reduce(self._dist) if world > 1 else None)
         self.model.count_batches(plan.K)        # BatchNorm2d bookkeeping: the plan applied the model K times in training mode
         self.model.flat_params.add_(0)          # bump the autograd version: autograd-path engines refresh their bf16 weights
@@ -190,6 +202,20 @@ class Trainer:
     # ------------------------------------------------------------------ epoch loops
     def _to_device(self, batch):
         return tuple(t.to(self.device, non_blocking=True) for t in batch)
+
+    def _shard(self, batch):
+        """Data parallel with a plain (unsharded) loader: every rank receives the same global batch and keeps rows
+        [rank*b, (rank+1)*b), b = batch/world -- the convention of HbmBatchLoader and SURVEY.md section 8e.  A loader that already
+        shards (DistributedSampler, HbmBatchLoader(rank=, world=)) declares it with `loader.sharded = True`."""
+        if self._dist is None or getattr(self.train_loader, "sharded", False) or \
+                type(getattr(self.train_loader, "sampler", None)).__name__ == "DistributedSampler":
+            return batch
+        n = batch[0].shape[0]
+        if n % self._world:
+            raise RuntimeError(f"data-parallel training: a global batch of {n} samples cannot be split over {self._world} ranks "
+                               "(use drop_last=True and a batch size divisible by the world size)")
+        b = n // self._world
+        return tuple(t[self._rank * b:(self._rank + 1) * b] for t in batch)
 
     def _train_epoch_hbm(self, loader) -> Dict[str, float]:
         """HbmBatchLoader + plan engine: every batch is gathered by one kernel straight into the plan's input buffers (no host
@@ -215,11 +241,15 @@ class Trainer:
         acc: Dict[str, float] = {}
         n = 0
         for batch in self.train_loader:
-            batch = self._to_device(batch)
+            batch = self._to_device(self._shard(batch))
             rollout = len(batch) == 3
             inputs, targets = batch[0], batch[1]
             masks = batch[2] if rollout else None
             d = self._native_step(inputs, targets, masks) if self.engine == "plan" else None
+            if d is None and self._dist is not None:
+                # the autograd fallback has no gradient all-reduce: refusing beats ranks that silently diverge
+                raise RuntimeError(f"no plan slot left for batch shape {tuple(inputs.shape)} under data parallelism (raise max_plans, "
+                                   "or use drop_last=True so that every batch has one shape)")
             if d is None:
                 self.optimizer.zero_grad()
                 if rollout:

@@ -147,6 +147,10 @@ int fnet_device_info(int32_t out[4]);
  * further is launched and *failed_index (if non-null) receives the op index.
  */
 int fnet_plan_run(const FnetOp* ops, int32_t n_ops, void* stream, int32_t* failed_index);
+/* The hipStream_t behind side lane `lane` (1 .. FNET_MAX_LANES-1) of the current device, created on first use and owned by the
+ * library.  No reference counterpart (the reference is single-stream): the data-parallel host uses it to order a gradient
+ * bucket's RCCL all-reduce behind the lane that produced the bucket's last piece (fluidnet_amd/training/dp.py). */
+int fnet_lane_stream(int32_t lane, void** stream_out);
 
 /*
  * hipGraph form of fnet_plan_run for launch-bound loops (the 600-frame rollout of
@@ -194,7 +198,8 @@ int fnet_timer_destroy(void* timer);
  *   fnet_rollout_create     allocates every device buffer (hipMalloc), uploads and re-lays the weights,
  *                           captures one frame in a hipGraph; synchronises
  *   fnet_rollout_set_weights / set_masks / set_state   host -> device uploads (null = zeros); synchronise
- *   fnet_rollout_add_impulse  velx += ix, vely += iy from a host [B][2][H][W] array (Simulation.cpp:263-271); async on `stream`
+ *   fnet_rollout_add_impulse  velx += ix, vely += iy from a host [B][2][H][W] array (Simulation.cpp:263-271) on `stream`; synchronises
+ *                           `stream` before returning, so the host array may be reused or freed at once
  *   fnet_rollout_step       `frames` graph replays on `stream`: state_prev <- density, state <- UNet(state, prev, masks)
  *   fnet_rollout_state_ptr  device pointers of the state [B][3][H][W] and the previous density [B][H][W]
  *   fnet_rollout_read_state device -> host copy of the state; synchronises `stream`

@@ -11,7 +11,9 @@ for K = 1, 2, 4 (ml/training/trainer.py:348-385), in two regimes:
       problem's conditioning and not the bf16 path is shown with the fp32 plan alone: run on weights and inputs rounded ONCE to
       bf16 (the "floor" run) it decorrelates from the exact fp32 run the same way.  K = 1 must agree; K >= 2 is bounded by the floor;
   (b) after 200 K1 Adam steps on a fixed batch -- the regime the reference's curriculum actually runs K4 in: K4 warm-starts from
-      trained K3 weights (ml/scripts/train.py:132-138).  This is the stated bf16 tolerance of the training step:
+      trained K3 weights (ml/scripts/train.py:132-138) -- with the gradients taken on ANOTHER batch of the same distribution (on the
+      training batch itself the K1 gradient sits at a minimum, norm 0.01, and its direction is rounding noise in any arithmetic).
+      This is the stated bf16 tolerance of the training step:
           loss within 2e-2 rel, final prediction rel-L2 <= 8e-2, whole-gradient cosine >= BAR_COS[K].
 The numbers of the last run are written to gpurun_out/k4_parity.json (per-tensor cosines included).
 """
@@ -32,7 +34,7 @@ from helpers import unpack
 
 pytestmark = pytest.mark.gpu
 B, R = 4, 128
-BAR_COS = {1: 0.98, 2: 0.96, 4: 0.97}          # trained regime; see DESIGN.md section 5 for the measured values
+BAR_COS = {1: 0.985, 2: 0.975, 4: 0.985}          # trained regime; see DESIGN.md section 5 for the measured values
 
 
 def _crit():
@@ -141,8 +143,9 @@ def test_bf16_vs_fp32_plan_at_random_init(batch, K):
 
 
 @pytest.mark.parametrize("K", [1, 2, 4])
-def test_bf16_vs_fp32_plan_after_training(batch, trained, K):
-    r = _compare(_run(_model("fp32", trained), "fp32", K, batch), _run(_model("bf16", trained), "bf16", K, batch), K)
+def test_bf16_vs_fp32_plan_after_training(trained, K):
+    held_out = synth_rollout_batch(B, 4, R, seed=8765)
+    r = _compare(_run(_model("fp32", trained), "fp32", K, held_out), _run(_model("bf16", trained), "bf16", K, held_out), K)
     _REPORT[f"trained/K{K}"] = r
     _dump()
     print(f"[k4 parity] trained K={K}: loss {r['loss16']:.5f} vs {r['loss32']:.5f}; pred rel-L2 per application {['%.3f' % v for v in r['pred_rel']]}; "

@@ -702,3 +702,52 @@ extern "C" int fnet_divergence(const float* velx, const float* vely, float* div,
     op.p[0] = (uint64_t)velx; op.p[1] = (uint64_t)vely; op.p[2] = (uint64_t)div;
     return fnet_op_stencil(op, (hipStream_t)stream);
 }
+
+// ---- allocation-free physics-loss terms (no counterpart in the reference) ----------------------------------------------------------
+// For callers that cannot call hipMalloc: code under hipGraph capture, the viewer's per-frame loop (live divergence / loss read-outs),
+// harnesses that forbid allocation.  Same kernels as the ZERO + LOSS_REDUCE + LOSS_FINALIZE ops of fnet_plan_run; the only scratch
+// those need -- the eight fp64 sums the reduce kernel adds into -- lives in this file-scope device array instead of a caller
+// buffer.  Every GPU the library runs on holds its own 256-byte copy until the process ends.  All calls on one GPU share it: it is
+// cleared at the start of every call, and calls that overlap on one GPU (two streams, two threads) race on it.
+static __device__ __align__(256) double scratch[8];
+static double* g_scratch_ptr[16];          // per device: the array's DEVICE address (the name above is only a host-side stand-in)
+
+#define FNET_NOALLOC_MAX_CELLS (1ll << 30)
+
+extern "C" int fnet_physics_loss_terms_noalloc(const float* pred, const float* target, const float* density_in, const float* emitter,
+                                               const float* collider, int32_t B, int32_t H, int32_t W, int32_t target_bstride,
+                                               int32_t density_bstride, int32_t emitter_bstride, int32_t collider_bstride,
+                                               int32_t padding_mode, int32_t stencil_mode, int32_t flags, float grid_spacing, float w_mse,
+                                               float w_div, float w_grad, float w_emit, float* terms_out, void* stream) {
+    if (B <= 0 || H <= 0 || W <= 0 || !terms_out) return FNET_E_BADARG;
+    if ((long long)B * H * W > FNET_NOALLOC_MAX_CELLS) return FNET_E_TOO_LARGE;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess || dev < 0 || dev >= 16) { g_fnet_last_hip_error = (int)e; return FNET_E_HIP; }
+    if (!g_scratch_ptr[dev]) {             // once per device, with that device current
+        double* p = nullptr;
+        e = hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p) { g_fnet_last_hip_error = (int)e; return FNET_E_HIP; }
+        g_scratch_ptr[dev] = p;
+    }
+    double* sums = g_scratch_ptr[dev];
+    hipStream_t st = (hipStream_t)stream;
+    FnetOp r = {};
+    r.op = FNET_OP_LOSS_REDUCE;
+    r.i[0] = B; r.i[1] = H; r.i[2] = W; r.i[3] = target_bstride; r.i[4] = density_bstride; r.i[5] = emitter_bstride; r.i[6] = collider_bstride;
+    r.i[7] = padding_mode; r.i[8] = stencil_mode; r.i[9] = flags;
+    r.f[0] = grid_spacing;
+    r.p[0] = (uint64_t)pred; r.p[1] = (uint64_t)target; r.p[2] = (uint64_t)density_in; r.p[3] = (uint64_t)emitter; r.p[4] = (uint64_t)collider;
+    r.p[5] = (uint64_t)sums;
+    if (!loss_args_ok(r)) return FNET_E_BADARG;        // before anything is queued
+    e = hipMemsetAsync(sums, 0, sizeof(double) * 8, st);            // the last call's sums
+    if (e != hipSuccess) { g_fnet_last_hip_error = (int)e; return FNET_E_HIP; }
+    int rc = fnet_op_loss_reduce(r, st);
+    if (rc != FNET_OK) return rc;
+    FnetOp f = {};
+    f.op = FNET_OP_LOSS_FINALIZE;
+    f.i[0] = B; f.i[1] = H; f.i[2] = W; f.i[3] = flags; f.i[4] = 1;
+    f.f[0] = w_mse; f.f[1] = w_div; f.f[2] = w_grad; f.f[3] = w_emit; f.f[4] = 1.f;
+    f.p[0] = (uint64_t)sums; f.p[2] = (uint64_t)terms_out;
+    return fnet_op_loss_finalize(f, st);
+}

@@ -121,6 +121,7 @@ const char* fnet_strerror(int code) {
         case FNET_E_BADARG: return "bad argument (shape, alignment or enum) -- nothing was launched for that op";
         case FNET_E_HIP: return "HIP runtime error (see fnet_last_hip_error)";
         case FNET_E_UNSUPPORTED: return "unsupported configuration";
+        case FNET_E_TOO_LARGE: return "input larger than the stated maximum of this allocation-free entry point -- nothing was launched";
         default: return "unknown error";
     }
 }

@@ -63,6 +63,8 @@ def lib() -> ctypes.CDLL:
     L.fnet_graph_launch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32]
     L.fnet_graph_destroy.restype = ctypes.c_int
     L.fnet_graph_destroy.argtypes = [ctypes.c_void_p]
+    L.fnet_physics_loss_terms_noalloc.restype = ctypes.c_int
+    L.fnet_physics_loss_terms_noalloc.argtypes = [fp] * 5 + [ctypes.c_int32] * 10 + [ctypes.c_float] * 5 + [fp, ctypes.c_void_p]
     L.fnet_lane_stream.restype = ctypes.c_int
     L.fnet_lane_stream.argtypes = [ctypes.c_int32, ctypes.POINTER(ctypes.c_void_p)]
     L.fnet_spatial_gradients.restype = ctypes.c_int
@@ -97,7 +99,7 @@ def lib() -> ctypes.CDLL:
     return L
 
 
-EXPORTS = ["fnet_abi_version", "fnet_strerror", "fnet_last_hip_error", "fnet_device_info", "fnet_plan_run", "fnet_lane_stream", "fnet_graph_create",
+EXPORTS = ["fnet_abi_version", "fnet_strerror", "fnet_last_hip_error", "fnet_device_info", "fnet_plan_run", "fnet_lane_stream", "fnet_physics_loss_terms_noalloc", "fnet_graph_create",
            "fnet_graph_launch", "fnet_graph_destroy", "fnet_spatial_gradients", "fnet_divergence", "fnet_timer_create",
            "fnet_timer_start", "fnet_timer_stop", "fnet_timer_elapsed_ms", "fnet_timer_destroy", "fnet_unet_param_count",
            "fnet_rollout_create", "fnet_rollout_set_weights", "fnet_rollout_set_masks", "fnet_rollout_set_state", "fnet_rollout_add_impulse",

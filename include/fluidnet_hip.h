@@ -35,6 +35,7 @@ extern "C" {
 #define FNET_E_BADARG (-1)   /* shape / alignment / enum violation (host-side check, nothing launched) */
 #define FNET_E_HIP (-2)      /* a HIP runtime call failed; fnet_last_hip_error() has the code */
 #define FNET_E_UNSUPPORTED (-3)
+#define FNET_E_TOO_LARGE (-4)  /* the input exceeds the stated maximum of an allocation-free entry point (nothing launched) */
 
 /* element type of P-tensors */
 #define FNET_F32 0
@@ -173,6 +174,23 @@ int fnet_spatial_gradients(const float* field, float* grad_x, float* grad_y, int
                            float dx, float dy, int32_t padding_mode, int32_t stencil_mode, void* stream);
 int fnet_divergence(const float* velx, const float* vely, float* div, int32_t B, int32_t H, int32_t W, float dx,
                     float dy, int32_t padding_mode, int32_t stencil_mode, void* stream);
+
+/*
+ * Allocation-free physics-loss terms.  NO counterpart in the reference: it exists for callers that cannot call hipMalloc -- code
+ * under hipGraph capture, the viewer's per-frame loop, harnesses that forbid allocation.  Computes the forward terms of
+ * PhysicsAwareLoss (ml/training/physics_loss.py:210-278) exactly as fnet_plan_run does for the op sequence ZERO(sums) + LOSS_REDUCE +
+ * LOSS_FINALIZE, but the eight fp64 sums those kernels need live in a 256-byte static __device__ array of the library (one copy per
+ * GPU, held until the process ends) instead of a caller buffer; no hipMalloc / hipFree / allocating routine is called.
+ *   pred [B,3,H,W]; target / density_in / emitter / collider: planes with the given batch strides (floats), as LOSS_REDUCE;
+ *   flags bit0 divergence, bit1 gradient, bit2 emitter term; terms_out: DEVICE float[8] = mse, divergence, gradient, emitter, total,
+ *   fluid-cell count (written on `stream`).
+ * Limit: B*H*W <= 2^30 cells, else FNET_E_TOO_LARGE.  All calls on one GPU share the array (cleared at the start of every call):
+ * calls that overlap on one GPU -- two streams or two threads -- race on it; serialise them.
+ */
+int fnet_physics_loss_terms_noalloc(const float* pred, const float* target, const float* density_in, const float* emitter,
+                                    const float* collider, int32_t B, int32_t H, int32_t W, int32_t target_bstride, int32_t density_bstride,
+                                    int32_t emitter_bstride, int32_t collider_bstride, int32_t padding_mode, int32_t stencil_mode, int32_t flags,
+                                    float grid_spacing, float w_mse, float w_div, float w_grad, float w_emit, float* terms_out, void* stream);
 
 /*
  * HIP-event timing of a stream region, on the stream the kernels were launched on (bench.py

@@ -95,8 +95,33 @@ def barrier(world):
     torch.cuda.synchronize()
 
 
+def synthetic_store(R, K, world, rank, batch, seed=1234):
+    """An HBM-resident synthetic dataset (BASELINE.md section 3 statistics) behind the reference's dataset API: seq_*.npz files written
+    to a temporary directory, read by FluidNPZSequenceDataset (preloaded: the reference's default), uploaded once by
+    HbmSequenceStore.  Every optimisation step then forms its batch with one GATHER_BATCH launch (flip augmentation included) inside
+    the timed region, rank-disjoint rows of one seeded permutation under data parallelism."""
+    import tempfile
+
+    from fluidnet_amd.dataset import FluidNPZSequenceDataset
+    from fluidnet_amd.dataset.hbm_resident import HbmBatchLoader, HbmSequenceStore
+    n_seq, T = 16, max(K + 3, (batch * world * 2) // 16 + K + 2)
+    tmp = tempfile.TemporaryDirectory(prefix="fnet_bench_")
+    d = os.path.join(tmp.name, "npz", "train")
+    os.makedirs(d)
+    for i in range(n_seq):
+        x0, y, mk = synth_rollout_batch(T, 1, R, seed=seed + 17 * i)
+        np.savez(os.path.join(d, f"seq_{i:04d}.npz"), density=x0[:, 0], velx=x0[:, 1], velz=x0[:, 2],
+                 emitter=np.repeat(mk[:1, 0, 0], T, 0), collider=np.repeat(mk[:1, 0, 1], T, 0))
+    ds = FluidNPZSequenceDataset(os.path.join(tmp.name, "npz"), "train", normalize=False, is_training=True,
+                                 augmentation_config={"enable_augmentation": True, "flip_probability": 0.5}, preload=True,
+                                 rollout_steps=K, stride=1)
+    store = HbmSequenceStore(ds)
+    tmp.cleanup()
+    return HbmBatchLoader(store, batch, shuffle=True, seed=seed, rank=rank, world=world)
+
+
 class TrainStepper:
-    def __init__(self, B, R, K, precision, world, rank, lr=3e-4, conv_impl="auto", arch="medium", depth=None):
+    def __init__(self, B, R, K, precision, world, rank, lr=3e-4, conv_impl="auto", arch="medium", depth=None, loader=True):
         torch.manual_seed(42)
         self.model = UNet(arch_cfg(arch, depth=depth), precision=precision, conv_impl=conv_impl).cuda()
         self.world, self.rank = world, rank
@@ -110,6 +135,9 @@ class TrainStepper:
         self.plan.y.tensor.copy_(torch.from_numpy(y))
         self.plan.masks.tensor.copy_(torch.from_numpy(mk))
         self.t = 0
+        # batch formation inside the step: a new batch per step from the HBM-resident store (K = 1 plans take the masks of frame t)
+        self.loader = synthetic_store(R, K, world, rank, B) if loader else None
+        self._batches, self._epoch = [], 0
         if world > 1:
             import torch.distributed as dist
             self.dist = dist
@@ -120,9 +148,19 @@ class TrainStepper:
             else:
                 dist.broadcast(self.model.flat_params, 0)
 
+    def next_batch(self):
+        if not self._batches:
+            self.loader.set_epoch(self._epoch)
+            self._batches = list(self.loader.batches())
+            self._epoch += 1
+        rows, flips = self._batches.pop()
+        self.loader.gather(rows, flips, self.plan.x0.tensor, self.plan.y.tensor, self.plan.masks.tensor)
+
     def step(self):
         self.t += 1
         p = self.plan
+        if self.loader is not None:
+            self.next_batch()
         p.set_adam_scalars(self.lr, self.t)
         p.set_dropout_seed(step_seed(self.t, self.rank))
         dp_train_step(p, self.world, torch_all_reduce(self.dist) if self.world > 1 else None)
@@ -192,30 +230,37 @@ def pmc_traffic(kernel):
         return None, None
 
 
-def cpu_baseline_train(K, R, budget_s=20.0):
-    """The CPU oracle (oracle/fluidnet_oracle.py, kind="port") timed on this host's cores on a bounded sample."""
+def cpu_baseline_train(K, R):
+    """The CPU oracle (oracle/fluidnet_oracle.py, kind="port") timed on this host's cores, SURVEY.md section 8d protocol: batch 8, fp32,
+    K = 1 and the benchmarked K, 3 warm-up + 5 timed optimisation steps each, median.  `value` is the benchmarked K's samples/s."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import fluidnet_oracle as orc
-    cores = os.cpu_count() or 1
-    threads = min(cores, 16) if os.environ.get("OMP_NUM_THREADS") is None else int(os.environ["OMP_NUM_THREADS"])
+    host_cpus = os.cpu_count() or 1
+    threads = min(host_cpus, 16) if os.environ.get("OMP_NUM_THREADS") is None else int(os.environ["OMP_NUM_THREADS"])
     torch.set_num_threads(threads)
-    B = 4
+    B = 8
     cfg = orc.medium_config(dropout=0.1)
     lc = orc.LossConfig(1.0, 0.01, 0.001, 0.01, 2.0 / R, True, True, True, "replicate", "forward")
-    p = orc.make_params(cfg, seed=7)
-    m = {k: torch.zeros_like(v) for k, v in p.items()}
-    v = {k: torch.zeros_like(t) for k, t in p.items()}
-    x0, y, mk = orc.synth_batch(B, K, R, seed=1234)
-    args = (torch.from_numpy(x0), torch.from_numpy(y), torch.from_numpy(mk))
-    orc.train_step(p, m, v, 1, cfg, lc, *args, lr=3e-4, clip_norm=1.0)      # warm-up
-    t0 = time.time()
-    n = 0
-    while n < 2 or (time.time() - t0 < budget_s and n < 8):
-        orc.train_step(p, m, v, n + 2, cfg, lc, *args, lr=3e-4, clip_norm=1.0)
-        n += 1
-    dt = (time.time() - t0) / n
-    return {"value": round(B / dt, 4), "unit": "samples/s", "cores": threads, "kind": "port",
-            "sample": f"oracle/fluidnet_oracle.py train_step, UNet_medium K{K} {R}x{R}, batch {B}, fp32, {n} timed steps of {dt:.2f}s after 1 warm-up"}
+    res = {}
+    for k in sorted({1, K}):
+        p = orc.make_params(cfg, seed=7)
+        m = {n: torch.zeros_like(v) for n, v in p.items()}
+        v = {n: torch.zeros_like(t) for n, t in p.items()}
+        x0, y, mk = orc.synth_batch(B, k, R, seed=1234)
+        args = (torch.from_numpy(x0), torch.from_numpy(y), torch.from_numpy(mk))
+        ts = []
+        for step in range(1, 9):
+            t0 = time.perf_counter()
+            orc.train_step(p, m, v, step, cfg, lc, *args, lr=3e-4, clip_norm=1.0)
+            ts.append(time.perf_counter() - t0)
+        res[k] = float(np.median(ts[3:]))
+    out = {"value": round(B / res[K], 4), "unit": "samples/s", "cores": threads, "host_cpus": host_cpus, "kind": "port",
+           "sample": f"oracle/fluidnet_oracle.py train_step, UNet_medium {R}x{R}, batch {B}, fp32, torch CPU with {threads} threads on a "
+                     f"{host_cpus}-CPU host; per K: 3 warm-up + 5 timed steps, median; K{K}: {res[K]:.2f} s/step"}
+    if K != 1:
+        out["k1_samples_per_s"] = round(B / res[1], 4)
+        out["sample"] += f", K1: {res[1]:.2f} s/step"
+    return out
 
 
 def cpu_baseline_rollout(R, budget_s=15.0):
@@ -240,6 +285,51 @@ def cpu_baseline_rollout(R, budget_s=15.0):
             "sample": f"oracle rollout_infer, UNet_medium {R}x{R}, {B} scenes, fp32, {n} timed frames of {dt:.2f}s"}
 
 
+def measure_rollout(a, R, batch, frames, warm, world, rank, profile=True, dump=None):
+    """BASELINE config 5: `frames` hipGraph replays of one autoregressive frame over `batch` scenes (ml/scripts/simple_infer.py:226-260)."""
+    torch.manual_seed(42)
+    model = UNet(arch_cfg(a.arch, dropout=0.0, depth=a.depth), precision=a.precision, conv_impl=a.conv_impl).cuda().eval()
+    plan = RolloutInferPlan(model.cfg, batch, R, R, params_flat=model.flat_params, dtype=a.precision, conv_impl=a.conv_impl,
+                            norm_state=model.flat_norm_state)
+    em, co = simple_infer_masks(R, scale=R / 128.0)
+    e = torch.from_numpy(em).cuda()[None].repeat(batch, 1, 1)
+    c = torch.from_numpy(co).cuda()[None].repeat(batch, 1, 1)
+    plan.reset(e, c)
+    plan.step(warm)
+    barrier(world)
+    t0 = time.perf_counter()
+    plan.step(frames)
+    barrier(world)
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
+    if world > 1:
+        import torch.distributed as dist
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    value = world * batch * frames / dt
+    fl = sum(r.flops for r in plan.frame)
+    out = {"metric": "rollout frames/sec", "value": round(value, 1), "unit": "scene-frames/s", "n_gpus": world, "steps": frames,
+           "warmup": warm, "ms_per_step": round(dt / frames * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
+           "config": {"workload": f"{frames}-frame autoregressive rollout, UNet_{a.arch} {R}x{R}, {batch} scenes/GPU, hipGraph-captured frame",
+                      "steps_per_s": round(frames / dt, 2), "parallelism": f"replicas{world}",
+                      "end_to_end_tflops": round(fl * frames / dt / 1e12, 2), "state_finite": bool(torch.isfinite(plan.cur.tensor).all())}}
+    if batch == 1 and R == 128 and world == 1 and a.arch in PUBLISHED_B1_128_FPS:
+        # the reference's own published configuration for this metric (other hardware, other runtime: see PUBLISHED_B1_128_FPS)
+        pub = PUBLISHED_B1_128_FPS[a.arch]
+        out["vs_baseline"] = round(value / pub, 2)
+        out["config"]["published"] = f"{1e3 / pub:g} ms/frame = {pub:g} frames/s, UNet_{a.arch} 128x128 batch 1, ORT CUDA EP on RTX 3070 (README.md:159-161)"
+    if rank == 0 and profile:
+        agg = profile_ops({"frame": plan._frame}, {"frame": plan.frame}, dump)
+        conv = agg.get("CONV3X3_MFMA") or agg.get("CONV3X3_REF")
+        ach = conv["flops"] / (conv["ms"] * 1e-3) / 1e12
+        out["roofline"] = {"bound": "mfma", "kernel": "k_conv3x3_dma", "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS,
+                           "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                           "launches_per_step": conv["n"], "avg_launch_ms": round(conv["ms"] / conv["n"], 4)}
+        out["breakdown_ms_per_step"] = {k: round(v["ms"], 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -254,6 +344,8 @@ def main():
     ap.add_argument("--precision", default="bf16")
     ap.add_argument("--conv-impl", default="auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-rollout", action="store_true", help="skip the short 256^2 x 64-scene rollout leg of the default training line")
+    ap.add_argument("--static-batch", action="store_true", help="reuse one resident batch instead of gathering a new one per step from the HBM-resident store")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--dump-ops", default=None, help="write per-op HIP-event timings of the instrumented step to this CSV")
     a = ap.parse_args()
@@ -268,7 +360,8 @@ def main():
         R = a.res or 128
         steps = a.steps if a.steps is not None else 10
         warm = a.warmup if a.warmup is not None else 3
-        st = TrainStepper(a.batch, R, a.k, a.precision, world, rank, conv_impl=a.conv_impl, arch=a.arch, depth=a.depth)
+        default_line = a.k == 4 and R == 128 and a.batch == 64 and a.precision == "bf16" and a.arch == "medium" and a.depth is None
+        st = TrainStepper(a.batch, R, a.k, a.precision, world, rank, conv_impl=a.conv_impl, arch=a.arch, depth=a.depth, loader=not a.static_batch)
         for _ in range(warm):
             st.step()
         barrier(world)
@@ -290,7 +383,9 @@ def main():
                "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": a.precision, "data": "synthetic",
                "config": {"workload": f"UNet_{a.arch}{'' if a.depth is None else f' depth {a.depth}'} K{a.k} rollout training {R}x{R}, batch {a.batch}/GPU, MSE+divergence+gradient+emitter, "
-                                      f"BPTT through all K, clip 1.0 + Adam, dropout {st.model.cfg.dropout}", "global_batch": a.batch * world,
+                                      f"BPTT through all K, clip 1.0 + Adam, dropout {st.model.cfg.dropout}; "
+                                      + ("a new batch per step gathered (flip augmentation included) from the HBM-resident store" if st.loader is not None
+                                         else "one static resident batch"), "global_batch": a.batch * world,
                           "parallelism": f"dp{world}", "final_loss": round(loss["total"], 6),
                           "hbm_bytes_allocated": st.bytes}}
         flops_step = sum(r.flops for s in st.plan.sections.values() for r in s)
@@ -316,50 +411,21 @@ def main():
                 out["wgrad_tflops"] = round(wg["flops"] / (wg["ms"] * 1e-3) / 1e12, 2)
         if rank == 0 and world == 1 and not a.no_cpu_baseline and a.arch == "medium":
             out["cpu_baseline"] = cpu_baseline_train(a.k, R)
+        if default_line and not a.no_rollout:
+            # the second half of BASELINE.json's metric ("rollout frames/sec", config 5) in the same line: 64 scenes at 256^2, the
+            # hipGraph-captured frame replayed 120 times after 10 warm-up frames (python bench.py --mode rollout runs all 600)
+            del st
+            torch.cuda.empty_cache()
+            ro = measure_rollout(a, 256, 64, 120, 10, world, rank, profile=not a.no_profile)
+            if rank == 0:
+                out["rollout"] = {"metric": ro["metric"], "value": ro["value"], "unit": ro["unit"], "frames": ro["steps"], "scenes_per_gpu": 64,
+                                  "resolution": 256, "ms_per_frame_step": ro["ms_per_step"], "state_finite": ro["config"]["state_finite"],
+                                  "conv_tflops": ro.get("roofline", {}).get("achieved"), "conv_frac": ro.get("roofline", {}).get("frac")}
     else:
         R = a.res or 256
         frames = a.steps if a.steps is not None else 600
         warm = a.warmup if a.warmup is not None else 10
-        torch.manual_seed(42)
-        model = UNet(arch_cfg(a.arch, dropout=0.0, depth=a.depth), precision=a.precision, conv_impl=a.conv_impl).cuda().eval()
-        plan = RolloutInferPlan(model.cfg, a.batch, R, R, params_flat=model.flat_params, dtype=a.precision, conv_impl=a.conv_impl,
-                                norm_state=model.flat_norm_state)
-        em, co = simple_infer_masks(R, scale=R / 128.0)
-        e = torch.from_numpy(em).cuda()[None].repeat(a.batch, 1, 1)
-        c = torch.from_numpy(co).cuda()[None].repeat(a.batch, 1, 1)
-        plan.reset(e, c)
-        plan.step(warm)
-        barrier(world)
-        t0 = time.perf_counter()
-        plan.step(frames)
-        barrier(world)
-        dt = time.perf_counter() - t0
-        tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        if world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-        value = world * a.batch * frames / dt
-        fl = sum(r.flops for r in plan.frame)
-        out = {"metric": "rollout frames/sec", "value": round(value, 1), "unit": "scene-frames/s", "n_gpus": world, "steps": frames,
-               "warmup": warm, "ms_per_step": round(dt / frames * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-               "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
-               "config": {"workload": f"{frames}-frame autoregressive rollout, UNet_{a.arch} {R}x{R}, {a.batch} scenes/GPU, hipGraph-captured frame",
-                          "steps_per_s": round(frames / dt, 2), "parallelism": f"replicas{world}",
-                          "end_to_end_tflops": round(fl * frames / dt / 1e12, 2), "state_finite": bool(torch.isfinite(plan.cur.tensor).all())}}
-        if a.batch == 1 and R == 128 and world == 1 and a.arch in PUBLISHED_B1_128_FPS:
-            # the reference's own published configuration for this metric (other hardware, other runtime: see PUBLISHED_B1_128_FPS)
-            pub = PUBLISHED_B1_128_FPS[a.arch]
-            out["vs_baseline"] = round(value / pub, 2)
-            out["config"]["published"] = f"{1e3 / pub:g} ms/frame = {pub:g} frames/s, UNet_{a.arch} 128x128 batch 1, ORT CUDA EP on RTX 3070 (README.md:159-161)"
-        if rank == 0 and not a.no_profile:
-            agg = profile_ops({"frame": plan._frame}, {"frame": plan.frame}, a.dump_ops)
-            conv = agg.get("CONV3X3_MFMA") or agg.get("CONV3X3_REF")
-            ach = conv["flops"] / (conv["ms"] * 1e-3) / 1e12
-            out["roofline"] = {"bound": "mfma", "kernel": "k_conv3x3_dma", "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS,
-                               "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
-                               "launches_per_step": conv["n"], "avg_launch_ms": round(conv["ms"] / conv["n"], 4)}
-            out["breakdown_ms_per_step"] = {k: round(v["ms"], 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
+        out = measure_rollout(a, R, a.batch, frames, warm, world, rank, profile=not a.no_profile, dump=a.dump_ops)
         if rank == 0 and world == 1 and not a.no_cpu_baseline and a.arch == "medium":
             out["cpu_baseline"] = cpu_baseline_rollout(R)
     if rank == 0:

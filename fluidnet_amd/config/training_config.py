@@ -9,9 +9,18 @@ config.yaml:1-24) are constants here; the MLflow names and variant bookkeeping a
 from __future__ import annotations
 
 from pathlib import Path
-from typing import Any, Dict, Optional, Tuple
+from typing import Any, Dict, Literal, Optional, Tuple
 
 from pydantic import BaseModel, create_model, field_validator
+
+# the closed value sets of the block options (ml/models/unet.py:9-14) and of the loss / schedule selectors: a YAML typo fails at load time
+NormType = Literal["none", "batch", "instance", "group"]
+ActType = Literal["relu", "leaky_relu", "gelu", "silu"]
+UpsampleType = Literal["nearest", "bilinear", "transpose"]
+DownsampleType = Literal["stride", "avgpool", "maxpool"]
+PaddingType = Literal["zeros", "reflect", "replicate", "circular"]
+OutputActivationType = Literal["sigmoid_tanh", "linear_clamp"]
+StencilMode = Literal["central", "forward"]
 
 GRID_RESOLUTION = 128      # config.yaml simulation.grid_resolution
 INPUT_CHANNELS = 6         # config.yaml simulation.input_channels
@@ -35,7 +44,7 @@ PhysicsLossConfig = _record("PhysicsLossConfig", {
     "gradient_weight": (float, 0.002), "emitter_weight": (float, 0.05),
     "enable_divergence": (bool, True), "enable_gradient": (bool, False), "enable_emitter": (bool, False),
     # finite-difference stencil ("forward" | "central") and cell size of the [-1, 1] domain
-    "stencil_mode": (str, "forward"), "grid_spacing": (float, 2.0 / GRID_RESOLUTION),
+    "stencil_mode": (StencilMode, "forward"), "grid_spacing": (float, 2.0 / GRID_RESOLUTION),
 }, doc="ml/config/training_config.py:10-20")
 
 AugmentationConfig = _record("AugmentationConfig", {
@@ -62,9 +71,9 @@ _DATA = {
 }
 _MODEL = {      # UNetConfig fields (models/unet.py), flattened into the training record as the reference does
     "in_channels": (int, INPUT_CHANNELS), "out_channels": (int, 3), "base_channels": (int, 32), "depth": (int, 3),
-    "norm": (str, "instance"), "act": (str, "gelu"), "group_norm_groups": (int, 8), "dropout": (float, 0.0),
-    "upsample": (str, "bilinear"), "downsample": (str, "stride"), "padding_mode": (str, "replicate"),
-    "use_residual": (bool, True), "bottleneck_blocks": (int, 1), "output_activation": (str, "linear_clamp"),
+    "norm": (NormType, "instance"), "act": (ActType, "gelu"), "group_norm_groups": (int, 8), "dropout": (float, 0.0),
+    "upsample": (UpsampleType, "bilinear"), "downsample": (DownsampleType, "stride"), "padding_mode": (PaddingType, "replicate"),
+    "use_residual": (bool, True), "bottleneck_blocks": (int, 1), "output_activation": (OutputActivationType, "linear_clamp"),
 }
 _BOOKKEEPING = {
     "mlflow_tracking_uri": (str, "./mlruns"), "mlflow_experiment_name": (str, "fluid_baseline_v1"),

@@ -277,7 +277,7 @@ class PlanBuilder:
         # stream).  Nothing on the data-gradient chain depends on them, and they are MFMA-bound where the normalisation / activation
         # adjoint kernels that follow on lane 0 are HBM- and VALU-bound, so the two overlap.  Buffers a side-lane launch reads are
         # held back from the temporary pool until the lanes are joined (emit_side_join, once per backward pass).
-        self.wgrad_lane = int(os.environ.get("FNET_WGRAD_LANE", "0")) if (training and dtype == "bf16") else 0
+        self.wgrad_lane = int(os.environ.get("FNET_WGRAD_LANE", "1")) if (training and dtype == "bf16") else 0
         self._n_events = 0
         self._side_reads: set = set()
         self._side_held: List[Buf] = []

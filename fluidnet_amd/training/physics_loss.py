@@ -197,57 +197,65 @@ class PhysicsAwareLoss(nn.Module):
 
 
 def _standalone(kind: str, a, b, emitter_mask, collider_mask, dx, padding_mode, mode) -> torch.Tensor:
-    """divergence_loss / gradient_loss as single-term PhysicsAwareLoss evaluations (same kernels)."""
+    """divergence_loss / gradient_loss as single-term PhysicsAwareLoss evaluations (same kernels).  The value returned is the
+    module's `total` with that one term at weight 1, so it is differentiable with respect to `a` (velx / density_pred) and, for
+    the divergence, `b` (vely) through LOSS_GRAD; the reference's gradient with respect to density_target is not provided."""
     _need_gpu(a, b, emitter_mask, collider_mask)
     a3, _ = _planes3(a)
     b3, _ = _planes3(b)
-    B, H, W = a3.shape
     z = torch.zeros_like(a3)
     em = z if emitter_mask is None else _planes3(emitter_mask)[0]
     co = z if collider_mask is None else _planes3(collider_mask)[0]
     if kind == "div":
         outputs = torch.stack([z, a3, b3], 1)
-        targets = outputs
+        targets = outputs.detach()
         crit = PhysicsAwareLoss(0.0, 1.0, 0.0, 0.0, dx, True, False, False, padding_mode, mode)
-        idx = 1
     else:
         outputs = torch.stack([a3, z, z], 1)
-        targets = torch.stack([b3, z, z], 1)
+        targets = torch.stack([b3.detach(), z, z], 1)
         crit = PhysicsAwareLoss(0.0, 0.0, 1.0, 0.0, dx, False, True, False, padding_mode, mode)
-        idx = 2
     inputs = torch.stack([z, z, z, z, em, co], 1)
-    _, terms = crit.forward_device(outputs, targets, inputs)
-    return terms[idx].clone()
+    total, _ = crit.forward_device(outputs, targets, inputs)
+    return total
 
 
 def divergence_loss(velx, vely, emitter_mask, collider_mask=None, dx: float = 1.0, dy: float = 1.0, eps: float = 1e-8,
                     padding_mode: str = "zeros", stencil_mode: StencilMode = "central") -> torch.Tensor:
-    """ml/training/physics_loss.py:94-126 (dx == dy and eps == 1e-8 as everywhere in the reference)."""
-    if dx != dy or eps != 1e-8:
-        raise NotImplementedError("fluidnet_amd: divergence_loss supports dx == dy and eps == 1e-8")
+    """ml/training/physics_loss.py:94-126.  dx != dy: the stencil is linear, so d(vx)/dx + d(vy)/dy is evaluated as the unit-spacing
+    divergence of (vx/dx, vy/dy).  eps is the kernels' compile-time 1e-8 (the only value the reference ever passes): anything
+    else is refused, not approximated."""
+    if eps != 1e-8:
+        raise NotImplementedError("fluidnet_amd: divergence_loss evaluates the masked mean with eps = 1e-8 (the reference's only value)")
+    if dx != dy:
+        return _standalone("div", velx / dx, vely / dy, emitter_mask, collider_mask, 1.0, padding_mode, stencil_mode)
     return _standalone("div", velx, vely, emitter_mask, collider_mask, dx, padding_mode, stencil_mode)
 
 
 def gradient_loss(density_pred, density_target, emitter_mask=None, collider_mask=None, dx: float = 1.0, dy: float = 1.0,
                   eps: float = 1e-8, padding_mode: str = "zeros", mode: StencilMode = "central") -> torch.Tensor:
-    """ml/training/physics_loss.py:129-166.  Without masks the reference takes plain L1 means (:162-164), which equals the
-    masked form with an all-fluid mask up to the 1e-8 in the denominator."""
+    """ml/training/physics_loss.py:129-166.  With emitter_mask=None the reference takes plain L1 means and IGNORES collider_mask
+    (:162-164); that branch is the masked form with an all-fluid mask (up to the 1e-8 in the denominator), so the collider is
+    dropped here too.  dx != dy or eps != 1e-8 are refused (the x and y sums share one kernel constant; the reference never
+    passes either)."""
     if dx != dy or eps != 1e-8:
-        raise NotImplementedError("fluidnet_amd: gradient_loss supports dx == dy and eps == 1e-8")
+        raise NotImplementedError("fluidnet_amd: gradient_loss supports dx == dy and eps == 1e-8 (the reference's only values)")
+    if emitter_mask is None:
+        collider_mask = None
     return _standalone("grad", density_pred, density_target, emitter_mask, collider_mask, dx, padding_mode, mode)
 
 
 def emitter_spawn_loss(density_pred, density_current, emitter_mask, threshold: float = 0.01) -> torch.Tensor:
-    """ml/training/physics_loss.py:169-177."""
+    """ml/training/physics_loss.py:169-177; differentiable with respect to density_pred.  threshold is the kernels' compile-time
+    0.01 (the reference's default and only value): anything else is refused."""
     if threshold != 0.01:
-        raise NotImplementedError("fluidnet_amd: emitter_spawn_loss supports threshold == 0.01")
+        raise NotImplementedError("fluidnet_amd: emitter_spawn_loss supports threshold == 0.01 (the reference's only value)")
     _need_gpu(density_pred, density_current, emitter_mask)
     d, _ = _planes3(density_pred)
     c, _ = _planes3(density_current)
     e, _ = _planes3(emitter_mask)
     z = torch.zeros_like(d)
     outputs = torch.stack([d, z, z], 1)
-    inputs = torch.stack([c, z, z, z, e, z], 1)
+    inputs = torch.stack([c.detach(), z, z, z, e, z], 1)
     crit = PhysicsAwareLoss(0.0, 0.0, 0.0, 1.0, 1.0, False, False, True)
-    _, terms = crit.forward_device(outputs, outputs, inputs)
-    return terms[3].clone()
+    total, _ = crit.forward_device(outputs, outputs.detach(), inputs)
+    return total

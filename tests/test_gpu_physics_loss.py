@@ -6,6 +6,8 @@ import numpy as np
 import pytest
 import torch
 
+import fluidnet_oracle as orc
+
 from fluidnet_amd.training.physics_loss import (PhysicsAwareLoss, compute_divergence, compute_spatial_gradients,
                                                 divergence_loss, emitter_spawn_loss, gradient_loss)
 
@@ -139,3 +141,37 @@ def test_g4_golden_matrix(golden_dir):
     assert abs(float(v) - float(g["nomask_gradient_loss"])) < 1e-5 * max(1, float(g["nomask_gradient_loss"]))
     v = emitter_spawn_loss(out[:, 0:1], inp[:, 0:1], torch.from_numpy(e[:, None]).to(D))
     assert abs(float(v) - float(g["emitter_loss"])) < 1e-7
+
+
+def test_standalone_losses_are_differentiable_and_follow_the_reference_branches():
+    """divergence_loss / gradient_loss / emitter_spawn_loss (ml/training/physics_loss.py:94-177) as autograd functions against the
+    oracle's torch autograd: values 1e-5 rel, gradients max-abs 1e-6 + 1e-5 of the largest element; dx != dy for the divergence;
+    gradient_loss with emitter_mask=None ignores a given collider mask exactly as the reference's l1 branch does."""
+    rs = np.random.RandomState(12)
+    B, H, W = 2, 20, 28
+    vx, vy, dp, dt = (torch.from_numpy(rs.normal(0, 0.5, (B, H, W)).astype(np.float32)) for _ in range(4))
+    dc = torch.from_numpy(rs.uniform(0, 0.05, (B, H, W)).astype(np.float32))
+    em = torch.from_numpy((rs.uniform(size=(B, H, W)) > 0.8).astype(np.float32))
+    co = torch.from_numpy((rs.uniform(size=(B, H, W)) > 0.85).astype(np.float32))
+
+    def both(fn_gpu, fn_cpu, diff_args, const_args, **kw):
+        ga = [a.clone().to(D).requires_grad_(True) for a in diff_args]
+        ca = [a.clone().requires_grad_(True) for a in diff_args]
+        vg = fn_gpu(*ga, *[None if c is None else c.to(D) for c in const_args], **kw)
+        vc = fn_cpu(*ca, *const_args, **kw)
+        assert abs(float(vg) - float(vc)) <= 1e-5 * max(1.0, abs(float(vc))), (float(vg), float(vc))
+        vg.backward()
+        vc.backward()
+        for a, b in zip(ga, ca):
+            assert float((a.grad.cpu() - b.grad).abs().max()) <= 1e-6 + 1e-5 * float(b.grad.abs().max())
+
+    for pm, st in (("replicate", "forward"), ("zeros", "central"), ("circular", "forward"), ("reflect", "central")):
+        both(divergence_loss, orc.divergence_loss, [vx, vy], [em, co], dx=0.25, dy=0.25, padding_mode=pm, stencil_mode=st)
+        both(divergence_loss, orc.divergence_loss, [vx, vy], [em, None], dx=0.5, dy=0.125, padding_mode=pm, stencil_mode=st)
+        both(gradient_loss, orc.gradient_loss, [dp], [dt, em, co], dx=0.25, dy=0.25, padding_mode=pm, mode=st)
+        both(gradient_loss, orc.gradient_loss, [dp], [dt, None, co], dx=0.25, dy=0.25, padding_mode=pm, mode=st)   # collider ignored
+    both(emitter_spawn_loss, orc.emitter_spawn_loss, [dp], [dc, em])
+    with pytest.raises(NotImplementedError):
+        gradient_loss(dp.to(D), dt.to(D), em.to(D), dx=1.0, dy=2.0)
+    with pytest.raises(NotImplementedError):
+        emitter_spawn_loss(dp.to(D), dc.to(D), em.to(D), threshold=0.5)

@@ -808,8 +808,8 @@ int fnet_wgrad_mfma(const FnetOp& op, hipStream_t st) {
         const int CW = 1 << log2cw, CH = WG_PX / CW;
         const int nch = B * ((W + CW - 1) / CW) * ((H + CH - 1) / CH);
         const int co_tiles = (Cout + 32 * nco - 1) / (32 * nco), ci_tiles = (Cin + 32 * nci - 1) / (32 * nci);
-        // two blocks per CU over the whole launch
-        static const int target_blocks = [] { const char* e = getenv("FNET_WG_BLOCKS"); return e ? atoi(e) : 512; }();
+        // one block per CU over the whole launch: the launch shares the chip with lane 0 (r2 sweep: 256 -> 38.10 ms, 512 -> 38.4 ms per K4 step)
+        static const int target_blocks = [] { const char* e = getenv("FNET_WG_BLOCKS"); return e ? atoi(e) : 256; }();
         int splits = (target_blocks + tiles - 1) / tiles;
         if (splits > nch) splits = nch;
         int cpb = (nch + splits - 1) / splits;
@@ -837,7 +837,7 @@ int fnet_wgrad_mfma(const FnetOp& op, hipStream_t st) {
 #undef WGD_LAUNCH
         const int elems = 9 * Cout * Cin;
         const int eb = (elems + kThreads - 1) / kThreads;
-        static const int red_blocks = [] { const char* e = getenv("FNET_WG_RED_BLOCKS"); return e ? atoi(e) : 1024; }();
+        static const int red_blocks = [] { const char* e = getenv("FNET_WG_RED_BLOCKS"); return e ? atoi(e) : 512; }();
         int groups = (red_blocks + eb - 1) / eb;
         if (groups > nparts) groups = nparts;
         const int ppg = (nparts + groups - 1) / groups;

@@ -692,7 +692,13 @@ class PlanBuilder:
     def _block_bwd(self, ops, units: List[Unit], srcs: List[GradSrc], residual: bool, need_dx: bool = True) -> List[GradSrc]:
         """Backward of a ConvBlock (residual=False) or ResBlock y = x + B(x) (residual=True); returns sources for x."""
         u1, u2 = units
-        g_a1, Gy = self._unit_bwd(ops, u2, srcs, need_G=residual)
+        # y = x + B(x): the gradient of y also reaches x directly.  With ONE incoming source that gradient is the source itself (read
+        # again, with its fold flag, by whoever consumes x's gradient): nothing is copied.  Two sources are summed once (G).
+        alias = None
+        if residual and len(srcs) == 1 and os.environ.get("FNET_KEEP_G", "0") != "1":
+            alias = GradSrc(srcs[0].pv, srcs[0].fold)
+            self.retain(alias.pv.buf)
+        g_a1, Gy = self._unit_bwd(ops, u2, srcs, need_G=residual and alias is None)
         if not residual and Gy is not None:
             self.release(Gy)
         g_x, G1 = self._unit_bwd(ops, u1, [g_a1], need_dx=need_dx)
@@ -702,7 +708,7 @@ class PlanBuilder:
         if g_x is not None:
             out.append(g_x)
         if residual:
-            out.append(GradSrc(PV(Gy, u2.out.C), 0))
+            out.append(alias if alias is not None else GradSrc(PV(Gy, u2.out.C), 0))
         return out
 
     def _plain_conv_bwd(self, ops, pc: PlainConv, srcs: List[GradSrc], need_dx: bool) -> Optional[GradSrc]:
@@ -718,6 +724,7 @@ class PlanBuilder:
                 p=[g1.pv.ref, g2.pv.ref if g2 else None, Ref(d)], tag=pc.conv)
         for s in srcs:
             self.release(s.pv.buf)
+        # (r2: on the weight-gradient lane this launch and the loss sums cost 0.13 ms per step more than they hide; they stay on lane 0)
         self.op(ops, "BIAS_GRAD", [B, H, W, C, C, 0], p=[Ref(d), self.gref(pc.conv + ".bias")], tag=pc.conv)
         if pc.stride == 2:
             full = self.tmp(2 * H, 2 * W, C)

@@ -70,36 +70,54 @@ def test_g3_rollout_k4_native_plan_fp32(golden_dir, tag, trunc, fin):
 
 
 def test_g7_adam_clip_native_plan_fp32(golden_dir):
+    """Step 1 is the fixture's arithmetic exactly.  From step 2 on the GPU's weights carry the first update's Adam noise (with
+    lr = 3e-3 an element whose clipped gradient is of the order of eps = 1e-8 -- a bias in front of an InstanceNorm: analytically zero --
+    moves anywhere in [-lr, lr] depending on the summation order), and three such steps are enough to move most elements of a
+    sensitive tensor (stem.weight) by a fraction of lr.  So every step is ALSO checked one step at a time against the oracle started
+    from the GPU's own parameters and moments (bias corrections of step 2 and 3, moment accumulation), and the oracle's three
+    steps are pinned to the fixture by tests/test_oracle_golden.py::test_g7_adam_clip."""
     g = np.load(os.path.join(golden_dir, "g7_adam_clip.npz"))
     cfg = tiny_cfg()
     m = _model(cfg, 19)
     plan = RolloutTrainPlan(m.cfg, _crit(loss_c2(32)), 2, 32, 32, 2, dtype="fp32", weight_decay=1.10, clip_norm=0.05)
     plan.bind(torch.device(DEV), m.flat_params, m.flat_grads)
+    names = list(plan.pb.shapes)
+    snap = lambda flat: {k: unpack(plan.pb, flat.detach(), k).cpu().clone() for k in names}  # noqa: E731
     for step in range(1, 4):
         x0, y, mk = orc.synth_batch(2, 2, 32, seed=700 + step)
         _fill(plan, x0, y, mk)
+        op, om, ov = snap(m.flat_params), snap(plan.m.tensor), snap(plan.v.tensor)
+        o_loss, _, o_raw = orc.train_step(op, om, ov, step, cfg, loss_c2(32), torch.from_numpy(x0), torch.from_numpy(y), torch.from_numpy(mk),
+                                          lr=3e-3, clip_norm=0.05)
         plan.set_adam_scalars(3e-3, step)
         dp_train_step(plan, 1)
         loss = plan.loss_dict()["total"]
-        ref = float(g[f"step{step}/loss"])
-        # step 1 is the fixture's arithmetic exactly; from step 2 on the weights carry the first update's Adam noise (see below: with
-        # lr = 3e-3 an element whose clipped gradient is of the order of eps moves anywhere in [-lr, lr]), which changes the loss in the
-        # 3rd digit and the gradient norm by a fraction of a percent
-        assert abs(loss - ref) < (1e-5 if step == 1 else 1e-2) * max(1.0, abs(ref)), (step, loss, ref)
         norm = float(torch.sqrt(plan.normsq.tensor[0]))
+        o_norm = float(torch.sqrt(sum((t.double() ** 2).sum() for t in o_raw.values())))
+        # against the oracle from the same state
+        assert abs(loss - o_loss) < 1e-5 * max(1.0, abs(o_loss)), (step, loss, o_loss)
+        assert abs(norm - o_norm) < 1e-3 * o_norm, (step, norm, o_norm)
+        got_p, got_m, got_v = snap(m.flat_params), snap(plan.m.tensor), snap(plan.v.tensor)
+        for k in names:
+            assert relerr(got_m[k], om[k], atol=1e-9) < 1e-3 and relerr(got_v[k], ov[k], atol=1e-14) < 2e-3, (step, k)
+            diff = (got_p[k] - op[k]).abs().numpy()
+            assert diff.max() <= 3e-3 * 1.01, (step, k, float(diff.max()))
+            if float(o_raw[k].norm()) >= 1e-6:
+                assert float((diff > 2e-5).mean()) < 0.02, (step, k, float((diff > 2e-5).mean()))
+        # against the fixture
+        ref = float(g[f"step{step}/loss"])
+        assert abs(loss - ref) < (1e-5 if step == 1 else 1e-2) * max(1.0, abs(ref)), (step, loss, ref)
         assert abs(norm - float(g[f"step{step}/grad_norm"])) < (1e-3 if step == 1 else 5e-2) * norm, (step, norm)
         if step in (1, 3):
-            for k in plan.pb.shapes:
-                got = unpack(plan.pb, m.flat_params.detach(), k).cpu().numpy()
-                diff = np.abs(got - g[f"step{step}/param/{k}"])
-                # Adam's update is lr * m / (sqrt(v) + eps): for an element whose (clipped) gradient is of the order of eps = 1e-8, or
-                # pure rounding noise (a bias in front of an InstanceNorm: analytically zero), the update is anything in [-lr, lr] and
-                # depends on the summation order of the gradient; everywhere else the fixture is matched closely
+            over = 0.0
+            for k in names:
+                diff = np.abs(got_p[k].numpy() - g[f"step{step}/param/{k}"])
                 assert diff.max() <= 3e-3 * step * 1.01, (step, k, float(diff.max()))
-                noise = float(unpack(plan.pb, m.flat_grads, k).norm()) < 1e-6
-                if not noise:
-                    tol = 2e-5 if step == 1 else 3e-4
-                    assert float((diff > tol).mean()) < (0.02 if step == 1 else 0.1), (step, k, float((diff > tol).mean()))
+                if step == 1 and float(o_raw[k].norm()) >= 1e-6:
+                    assert float((diff > 2e-5).mean()) < 0.02, (step, k, float((diff > 2e-5).mean()))
+                over = max(over, float((diff > 3e-4).mean()))
+            print(f"[G7] step {step}: loss {loss:.6f} (fixture {ref:.6f}); largest fraction of a tensor's elements further than 3e-4 "
+                  f"from the fixture: {over:.3f}")
 
 
 @pytest.mark.parametrize("precision,base", [("fp32", 8), ("bf16", 16)])

@@ -59,42 +59,59 @@ typedef const __attribute__((address_space(1))) void gbl_void_t;
 #ifndef FNET_CONV_STAMPS
 #define FNET_CONV_STAMPS 0
 #endif
-// FNET_CONV_WREG=1 (experiment, measured and not kept): the weight slab of a stage goes global -> VGPR -> ds_write_b128 instead of
-// LDS-DMA (the input run stays on DMA), on the reasoning that the kernel is bound by DMA issue and the weights are 9*TN/32 of a stage's
-// pieces.  Parity-green, but the convolutions of a K4 B64 step took 17.5 ms instead of 16.1: the wave must itself wait for the loads,
-// store and wait again before the stage barrier, where a DMA piece lands on its own.
-#ifndef FNET_CONV_WREG
-#define FNET_CONV_WREG 0
-#endif
-
+// ---- stride-2 convolutions as 2x2-tap convolutions over a space-to-depth view (MODE 1 / MODE 2) ----------------------------
+// Conv2d(C, Co, 3, stride 2, padding 1) on an H x W image (ml/models/unet.py:90-91) reads, for output (y, x), the padded rows
+// 2y, 2y+1, 2y+2 of the source P-tensor.  Pair the PADDED rows and columns, (0,1), (2,3), ...: X'[Y'][X'][(py, px, c)] =
+// Xp[2Y' + py][2X' + px][c] is an (h+1) x (w+1) image of 4C channels (h = H/2), and the convolution becomes a 2x2-tap, stride-1
+// convolution over X' whose tap (dy, dx) carries W[ky = 2dy + py][kx = 2dx + px] (zero where ky or kx would be 3): 16*C*Co MACs per
+// output instead of the 36*C*Co of the full-resolution convolution + subsampling it replaces.  X' is never stored:
+//   MODE 1 (forward): GEMM pixels = the half-resolution padded output space; the LDS-DMA of the input run gathers X' rows straight
+//           from the full-resolution P-tensor (per-lane source offsets, computed once per tile);
+//   MODE 2 (data gradient): dX'[Y'][X'] = sum_t Wd'[t] dOut[Y' + ty][X' + tx] (dOut = half-resolution gradient, ring zero), GEMM N
+//           = 4C; the epilogue scatters channel block (py, px) of pixel (Y', X') to dXp[2Y' + py][2X' + px]: every cell of the
+//           full-resolution padded gradient is written exactly once, ring included (a "folded" gradient source, like every dgrad).
+// Both walk the 2x2 window {0, 1} x {0, 1} from the window origin: f0 - Wp - 1 (MODE 1: taps reach up/left) or f0 (MODE 2).
 struct ConvTile {          // wave-uniform description of one (pixel tile, cout tile) work item
     long long f0;
     int n0;
-    int in_lane_off;       // per lane
+    int in_lane_off;       // per lane (MODE 0, 2)
     __amdgpu_buffer_rsrc_t rs;
 };
+constexpr int S2_MAXP = 8;  // MODE 1: DMA pieces per wave and stage whose gather offsets are kept in registers
+
+// exact a / d for 0 <= a < 2^24, d > 0, inv = 1.f / d
+__device__ __forceinline__ int fdiv24(int a, int d, float inv) {
+    int q = (int)((float)a * inv);
+    const int r = a - q * d;
+    if (r < 0) --q;
+    else if (r >= d) ++q;
+    return q;
+}
 
 // Two block shapes: NW = 4 waves (256 pixels per tile, two blocks per CU) and NW = 8 waves (512 pixels per tile, one block
 // per CU, TN up to 128).  The kernel is bound by the LDS-DMA issue rate (every 1-KB piece costs its wave 60-185 cycles,
 // MI355X_MICROARCH.md), i.e. by bytes staged per FLOP: per 16-channel stage a tile stages 9*TN weight rows + (TM + 2Wp + 2)
 // pixels for TM*TN*9 MACs, so the 512 x 128 tile stages 2.3x fewer bytes per FLOP than the 256 x 64 one; the small tile
 // remains for layers with too few tiles to fill 256 big-tile blocks.
-template <int TN, int NW>
+struct ConvS2 {            // MODE 1 / 2 geometry (half-resolution space: Hh rows, Wp - 2 columns; Cs channels per phase)
+    int Hh, Cs, HpWp;
+    float inv_hpwp, inv_wp, inv_cs;
+};
+
+template <int TN, int NW, int MODE>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_conv3x3_dma(const bf16_t* __restrict__ src, const bf16_t* __restrict__ Wk,
                                                         const float* __restrict__ bias, bf16_t* __restrict__ dst, int Npix, int Wp,
                                                         int Cin, int ldc_in, int coff_in, int Cout, int ldc_out, int coff_out,
-                                                        int n_mtiles, int n_ntiles, int rinp, int bufsz, float* __restrict__ stats_part,
-                                                        int H, int W) {
+                                                        int n_mtiles, int n_ntiles, int rinp, int bufsz, float* __restrict__ stamps,
+                                                        ConvS2 g2) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-#if FNET_CONV_STAMPS
-    float* stamps = stats_part;
-    stats_part = nullptr;
-#endif
     constexpr int TMB = NW * 64;                    // pixels per tile
     constexpr int NTHR = NW * 64;
     constexpr int NT = TN / 32;
-    constexpr int WB = 9 * TN * 32;                 // weight image bytes
-    constexpr int NPW = 9 * TN / 32;                // weight DMA pieces per stage
+    constexpr int NTAPS = MODE ? 4 : 9;
+    constexpr int TW = MODE ? 2 : 3;                // taps per window row
+    constexpr int WB = NTAPS * TN * 32;             // weight image bytes
+    constexpr int NPW = NTAPS * TN / 32;            // weight DMA pieces per stage
     const int npi = rinp >> 5;                      // input DMA pieces per stage
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -107,13 +124,38 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_conv3x3_dma(const 
     // each XCD a contiguous range of pixel tiles and run the cout tiles of one pixel tile back to back on it.
     const int cpx = (n_mtiles + 7) >> 3;
     const int n_items = 8 * cpx * n_ntiles;
-    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)Wk, 0, 9 * Cout * nst * KC * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)Wk, 0, NTAPS * Cout * nst * KC * 2, 0x00020000);
     const int swz = (lane >> 4) & 1;                // bit 3 of the row a DMA lane fills (row = 32*piece + lane/2)
     const int dh = (lane & 1) ^ swz;                // channel half this lane fetches
     const int in_piece_stride = 32 * ldc_in * 2;
     const int wrow = lane >> 1;                     // weight source: row = 32*piece + lane/2 -> (tap, col)
+    const int win0 = MODE == 2 ? 0 : Wp + 1;        // the window starts this many pixels before the tile
 
-    auto tile_of = [&](int L, ConvTile& T) -> bool {
+    // MODE 1: the whole full-resolution source through one descriptor; a lane's gather offsets for the pieces its wave issues
+    // (piece q = wave + NW * k <-> register k) are recomputed per tile, the stage adds a wave-uniform (phase, channel) offset
+    const int Hps = 2 * g2.Hh + 2, Wps = 2 * (Wp - 2) + 2;
+    __amdgpu_buffer_rsrc_t rsg = rsw;
+    if (MODE == 1) {
+        const long long bytes = (long long)(Npix / g2.HpWp) * Hps * Wps * ldc_in * 2;
+        rsg = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, (int)bytes, 0x00020000);
+    }
+    auto gather_off = [&](long long f0, int k) -> int {
+        const int q = wave + NW * k;
+        const long long P = f0 - win0 + q * 32 + (lane >> 1);      // pixel of X' (half-resolution padded, flattened)
+        if (q >= npi || P < 0 || P >= Npix) return 0x7ffffff0;     // out of range: the DMA writes zeros
+        const int n = fdiv24((int)P, g2.HpWp, g2.inv_hpwp);
+        const int rem = (int)P - n * g2.HpWp;
+        const int Y = fdiv24(rem, Wp, g2.inv_wp), X = rem - Y * Wp;
+        if (Y > g2.Hh || X > Wp - 2) return 0x7ffffff0;            // X' has (h+1) x (w+1) cells
+        return (((n * Hps + 2 * Y) * Wps + 2 * X) * ldc_in + coff_in + dh * 8) * 2;
+    };
+    auto stage_off = [&](int s) -> int {           // MODE 1: channel block 16s of the 4C axis = (phase, c0)
+        const int ph = (int)((float)(s * KC) * g2.inv_cs + 0.001f);          // C is a multiple of 16: the quotient is far from a boundary
+        const int c0 = s * KC - ph * g2.Cs;
+        return (((ph >> 1) * Wps + (ph & 1)) * ldc_in + c0) * 2;
+    };
+
+    auto tile_of = [&](int L, ConvTile& T, int (&so)[S2_MAXP]) -> bool {
         // returns false when L is past the end or maps to a padding slot of the XCD layout
         if (L >= n_items) return false;
         const int xcd = L & 7, j = L >> 3;
@@ -121,7 +163,14 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_conv3x3_dma(const 
         if (mt >= n_mtiles) return false;
         T.f0 = (long long)mt * TMB;
         T.n0 = (j - (j / n_ntiles) * n_ntiles) * TN;
-        const long long gbase = T.f0 - Wp - 1;
+        if (MODE == 1) {
+#pragma unroll
+            for (int k = 0; k < S2_MAXP; ++k) so[k] = gather_off(T.f0, k);
+            T.rs = rsg;
+            T.in_lane_off = 0;
+            return true;
+        }
+        const long long gbase = T.f0 - win0;
         const long long wpix = gbase > 0 ? gbase : 0;
         long long wbytes = ((long long)Npix - wpix) * ldc_in * 2;
         const long long wmax = (long long)(rinp + 1) * ldc_in * 2;
@@ -131,51 +180,34 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_conv3x3_dma(const 
         return true;
     };
     // one DMA piece (1 KB = 32 rows x 32 B) of stage s of tile T into stage buffer `buf`: pieces [0, npi) are the input run,
-    // [npi, npi + NPW) the weight slab
-    auto issue_piece = [&](const ConvTile& T, int s, int buf, int q) {
+    // [npi, npi + NPW) the weight slab.  k = the piece's register slot (q = wave + NW * k), sgo = stage_off(s) (MODE 1)
+    auto issue_piece = [&](const ConvTile& T, const int (&so)[S2_MAXP], int s, int sgo, int buf, int q, int k) {
         unsigned char* wdst = smem + buf * bufsz;
         if (q < npi) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(T.rs, (lds_void_t*)(wdst + WB + q * 1024), 16,
-                                                     T.in_lane_off + q * in_piece_stride + s * (KC * 2), 0, 0, 0);
+            if (MODE == 1)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(T.rs, (lds_void_t*)(wdst + WB + q * 1024), 16, so[k], sgo, 0, 0);
+            else
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(T.rs, (lds_void_t*)(wdst + WB + q * 1024), 16,
+                                                         T.in_lane_off + q * in_piece_stride + s * (KC * 2), 0, 0, 0);
         } else {
             const int qw = q - npi;
             const int row = qw * 32 + wrow;
             const int t = row / TN;
             int co = T.n0 + (row - t * TN);
             co = co < Cout ? co : Cout - 1;
-            const int woff = (int)(((((size_t)s * 9 + t) * Cout + co) * 16 + dh * 8) * 2);
+            const int woff = (int)(((((size_t)s * NTAPS + t) * Cout + co) * 16 + dh * 8) * 2);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_void_t*)(wdst + qw * 1024), 16, woff, 0, 0, 0);
         }
     };
-    constexpr bool WREG = FNET_CONV_WREG != 0 && TN <= 64;   // the 512 x 128 tile has no registers to spare (256 VGPRs)
-    const int npieces = WREG ? npi : npi + NPW;    // DMA pieces per stage
-    constexpr int WPW = (NPW + NW - 1) / NW;       // weight pieces per wave on the register path
-    static_assert(WPW <= 5, "weight pieces per wave");
-    uint4 w0 = {}, w1 = {}, w2 = {}, w3 = {}, w4 = {};
-    // (macros over five named registers, not lambdas over an array: hipcc left the array in scratch)
-#define FNET_WL1(k_, var_, T_, s_)                                                                                         \
-    if (k_ < WPW && wave + NW * k_ < NPW) {                                                                                \
-        const int row_ = (wave + NW * k_) * 32 + wrow;                                                                     \
-        const int tt_ = row_ / TN;                                                                                         \
-        int co_ = (T_).n0 + (row_ - tt_ * TN);                                                                             \
-        co_ = co_ < Cout ? co_ : Cout - 1;                                                                                 \
-        var_ = *reinterpret_cast<const uint4*>(Wk + ((((size_t)(s_) * 9 + tt_) * Cout + co_) * 16 + dh * 8));              \
-    }
-#define FNET_WLOAD(T_, s_) FNET_WL1(0, w0, T_, s_) FNET_WL1(1, w1, T_, s_) FNET_WL1(2, w2, T_, s_) FNET_WL1(3, w3, T_, s_) FNET_WL1(4, w4, T_, s_)
-#define FNET_WS1(k_, var_, buf_)                                                                                           \
-    if (k_ < WPW && wave + NW * k_ < NPW) *reinterpret_cast<uint4*>(smem + (buf_) * bufsz + (wave + NW * k_) * 1024 + lane * 16) = var_;
-#define FNET_WSTORE(buf_) FNET_WS1(0, w0, buf_) FNET_WS1(1, w1, buf_) FNET_WS1(2, w2, buf_) FNET_WS1(3, w3, buf_) FNET_WS1(4, w4, buf_)
-    auto issue = [&](const ConvTile& T, int s, int buf) {
-        for (int q = wave; q < npieces; q += NW) issue_piece(T, s, buf, q);
-    };
+    const int npieces = npi + NPW;                 // DMA pieces per stage (host: at most S2_MAXP per wave in MODE 1)
 
-    // fragment read addresses (bytes, relative to a stage buffer): 9 taps x 2 pixel sub-tiles; weights: lane base + immediates
-    unsigned xaddr[9][2];
+    // fragment read addresses (bytes, relative to a stage buffer): taps x 2 pixel sub-tiles; weights: lane base + immediates
+    unsigned xaddr[NTAPS][2];
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < NTAPS; ++t)
 #pragma unroll
         for (int ms = 0; ms < 2; ++ms) {
-            const int p = wave * 64 + ms * 32 + r + (t / 3) * Wp + (t % 3);
+            const int p = wave * 64 + ms * 32 + r + (t / TW) * Wp + (t % TW);
             xaddr[t][ms] = WB + (unsigned)(2 * p + (h ^ ((p >> 3) & 1))) * 16;
         }
     const unsigned waddr = (unsigned)(2 * r + (h ^ ((r >> 3) & 1))) * 16;
@@ -189,22 +221,27 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_conv3x3_dma(const 
             for (int i = 0; i < 16; ++i) acc[ms][ns][i] = 0.f;
 
     ConvTile cur, nxt;
-    bool have = tile_of(blockIdx.x, cur);
+    int so_cur[S2_MAXP], so_nxt[S2_MAXP];
+    bool have = tile_of(blockIdx.x, cur, so_cur);
     if (!have) return;
     int L = blockIdx.x;
     unsigned g = 0;                       // running stage counter: stage buffer = g & 1
 #if FNET_CONV_STAMPS
     // diagnostic build (tools/conv_bench.py): wave 0 of every block adds its cycles spent waiting at the stage barrier, in the
-    // tap loops, in the epilogue and in total to the first 5 int64 of the statistics scratch (no statistics in this build)
+    // tap loops, in the epilogue and in total to the first 5 int64 of `stamps`
     long long st_bar = 0, st_loop = 0, st_epi = 0, st_t0 = __builtin_amdgcn_s_memtime(), st_a, st_b;
 #define STAMP(x) x = __builtin_amdgcn_s_memtime()
 #else
 #define STAMP(x)
 #endif
-    issue(cur, 0, 0);
-    if (WREG) {
-        FNET_WLOAD(cur, 0)
-        FNET_WSTORE(0)
+    {
+        const int sgo = MODE == 1 ? stage_off(0) : 0;
+#pragma unroll
+        for (int k = 0; k < S2_MAXP; ++k) {
+            const int q = wave + NW * k;
+            if (q < npieces) issue_piece(cur, so_cur, 0, sgo, 0, q, k);
+        }
+        for (int q = wave + NW * S2_MAXP; q < npieces; q += NW) issue_piece(cur, so_cur, 0, sgo, 0, q, 0);   // MODE 0 / 2 only
     }
     while (true) {
         bool have_next = false;
@@ -219,10 +256,14 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_conv3x3_dma(const 
             // issued one piece per tap INSIDE the tap loop below: a piece costs the issuing wave 60-185 cycles, which hide behind
             // the four MFMAs of a tap instead of delaying every wave's first MFMA after the barrier.
             const bool last = s + 1 == nst;
-            if (last) { L += gridDim.x; have_next = tile_of(L, nxt); }
+            if (last) { L += gridDim.x; have_next = tile_of(L, nxt, so_nxt); }
             ConvTile Ti = cur;             // by value (a reference to one of two structs would put both in scratch)
+            int so_i[S2_MAXP];
+#pragma unroll
+            for (int k = 0; k < S2_MAXP; ++k) so_i[k] = last ? so_nxt[k] : so_cur[k];
             if (last) Ti = nxt;
             const int si = last ? 0 : s + 1;
+            const int sgo = MODE == 1 ? stage_off(si) : 0;
             const int nbuf = (g + 1) & 1;
 #if FNET_CONV_ABLATE == 2
             const int qlim = 0;
@@ -230,7 +271,6 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_conv3x3_dma(const 
             const int qlim = (!last || have_next) ? npieces : 0;
 #endif
             const unsigned bb = (g & 1) ? (unsigned)bufsz : 0u;
-            if (WREG && qlim) { FNET_WLOAD(Ti, si) }      // next stage's weights: in flight for the whole tap loop, stored after it
             // fragment reads run one tap ahead of the MFMAs (two register sets, static indexing after unrolling)
             bf16x8 xb[2][2], wa[2][NT];
 #pragma unroll
@@ -238,9 +278,9 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_conv3x3_dma(const 
 #pragma unroll
             for (int ns = 0; ns < NT; ++ns) wa[0][ns] = *reinterpret_cast<const bf16x8*>(smem + waddr + bb + (ns * 32) * 32);
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
+            for (int t = 0; t < NTAPS; ++t) {
                 const int c = t & 1, n = c ^ 1;
-                if (t + 1 < 9) {
+                if (t + 1 < NTAPS) {
 #pragma unroll
                     for (int ms = 0; ms < 2; ++ms) xb[n][ms] = *reinterpret_cast<const bf16x8*>(smem + xaddr[t + 1][ms] + bb);
 #pragma unroll
@@ -249,7 +289,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_conv3x3_dma(const 
                 }
                 {
                     const int q = wave + NW * t;
-                    if (q < qlim) issue_piece(Ti, si, nbuf, q);
+                    if (q < qlim) issue_piece(Ti, so_i, si, sgo, nbuf, q, t < S2_MAXP ? t : 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of this tap's MFMAs (hipcc otherwise re-serialises them)
 #pragma unroll
@@ -262,8 +302,13 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_conv3x3_dma(const 
                         acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[c][ns], xb[c][ms], acc[ms][ns], 0, 0, 0);
 #endif
             }
-            for (int q = wave + NW * 9; q < qlim; q += NW) issue_piece(Ti, si, nbuf, q);   // wide images: more than 9 pieces per wave
-            if (WREG && qlim) { FNET_WSTORE(nbuf) }
+            // more pieces per wave than taps (wide images; always in the 2x2 modes)
+#pragma unroll
+            for (int k = NTAPS; k < S2_MAXP; ++k) {
+                const int q = wave + NW * k;
+                if (q < qlim) issue_piece(Ti, so_i, si, sgo, nbuf, q, k);
+            }
+            for (int q = wave + NW * (NTAPS > S2_MAXP ? NTAPS : S2_MAXP); q < qlim; q += NW) issue_piece(Ti, so_i, si, sgo, nbuf, q, 0);
 #if FNET_CONV_STAMPS
             STAMP(st_a);
             st_loop += st_a - st_b;
@@ -312,92 +357,30 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_conv3x3_dma(const 
             }
             __syncthreads();
             const bool cvalid = n0 + chunk * 8 < Cout;
-            if (NW != 4 || TN > 64 || !stats_part) {
-                if (cvalid) {
-#pragma unroll
-                    for (int k = 0; k < TMB / PPI; ++k) {
-                        const int px = px0 + k * PPI;
-                        const long long f = f0 + px;
-                        if (f < Npix) {
-                            const uint4 v = *reinterpret_cast<const uint4*>(ot + px * PO + (((chunk ^ px) & (CH - 1)) << 4));
-                            st_stream16(dst + (size_t)f * ldc_out + coff_out + n0 + chunk * 8, v);
-                        }
-                    }
+            if (cvalid) {
+                // MODE 2: this thread's 8 channels are channels c .. c+7 of phase (py, px) of the full-resolution gradient
+                int ph_off = 0;
+                if (MODE == 2) {
+                    const int chn = n0 + chunk * 8;
+                    const int ph = (int)((float)chn * g2.inv_cs + 0.001f);       // C is a multiple of 8
+                    ph_off = ((ph >> 1) * Wps + (ph & 1)) * ldc_out + (chn - ph * g2.Cs);
                 }
-            } else {
-                // Fused InstanceNorm statistics (ml/models/unet.py:22-23), small-tile kernel only: while the tile streams out,
-                // every thread (fixed 8-channel chunk) sums x and x^2 of the bf16 values it stores, over interior pixels only,
-                // separately for the (at most two) images the tile touches (host guarantees (H+2)(W+2) >= 256).  Lanes that own
-                // the same chunk are combined with wave shuffles, the four waves through 2 KB of LDS, and the block partial
-                // goes to stats_part[tile][slot 0/1][Cout][2] with plain stores; IN_STATS (tile mode) adds them in tile order.
-                const int Hp = H + 2, HpWp = Hp * Wp;
-                const int n_first = (int)(f0 / HpWp);
-                const long long f_last = (f0 + TMB - 1 < Npix ? f0 + TMB - 1 : (long long)Npix - 1);
-                const int nslots = ((int)(f_last / HpWp) != n_first) ? 2 : 1;
-                float sa[2][8], qa[2][8];
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) { sa[s2][k] = 0.f; qa[s2][k] = 0.f; }
-                const int fi = (int)f0 + px0;
-                int n = fi / HpWp;
-                const int rem = fi - n * HpWp;
-                int y = rem / Wp, x = rem - y * Wp;
 #pragma unroll
                 for (int k = 0; k < TMB / PPI; ++k) {
                     const int px = px0 + k * PPI;
                     const long long f = f0 + px;
-                    if (f < Npix && cvalid) {
+                    if (f < Npix) {
                         const uint4 v = *reinterpret_cast<const uint4*>(ot + px * PO + (((chunk ^ px) & (CH - 1)) << 4));
-                        st_stream16(dst + (size_t)f * ldc_out + coff_out + n0 + chunk * 8, v);
-                        if (y >= 1 && y <= H && x >= 1 && x <= W) {
-                            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-                            const bool second = n != n_first;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const float lo = __uint_as_float(w[e] << 16), hi = __uint_as_float(w[e] & 0xffff0000u);
-                                if (second) {
-                                    sa[1][2 * e] += lo; qa[1][2 * e] = fmaf(lo, lo, qa[1][2 * e]);
-                                    sa[1][2 * e + 1] += hi; qa[1][2 * e + 1] = fmaf(hi, hi, qa[1][2 * e + 1]);
-                                } else {
-                                    sa[0][2 * e] += lo; qa[0][2 * e] = fmaf(lo, lo, qa[0][2 * e]);
-                                    sa[0][2 * e + 1] += hi; qa[0][2 * e + 1] = fmaf(hi, hi, qa[0][2 * e + 1]);
-                                }
-                            }
+                        if (MODE == 2) {
+                            const int n = fdiv24((int)f, g2.HpWp, g2.inv_hpwp);
+                            const int rem = (int)f - n * g2.HpWp;
+                            const int Y = fdiv24(rem, Wp, g2.inv_wp), X = rem - Y * Wp;
+                            if (Y <= g2.Hh && X <= Wp - 2)
+                                st_stream16(dst + (size_t)((n * Hps + 2 * Y) * Wps + 2 * X) * ldc_out + coff_out + ph_off, v);
+                        } else {
+                            st_stream16(dst + (size_t)f * ldc_out + coff_out + n0 + chunk * 8, v);
                         }
                     }
-                    x += PPI;
-                    while (x >= Wp) { x -= Wp; ++y; }
-                    if (y >= Hp) { y -= Hp; ++n; }
-                }
-                // lanes l and l + CH, l + 2CH, ... own the same chunk: butterfly over those lane bits, then lanes 0..CH-1
-                // hold the wave's sums
-                float* red = reinterpret_cast<float*>(ot + TMB * PO);     // [4 waves][CH][16] floats
-                const int mtile = (int)(f0 / TMB);
-                float* out = stats_part + ((size_t)mtile * 2) * Cout * 2;
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    float v16[16];
-                    if (s2 < nslots) {
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) { v16[k] = s2 ? sa[1][k] : sa[0][k]; v16[8 + k] = s2 ? qa[1][k] : qa[0][k]; }
-#pragma unroll
-                        for (int off = CH; off < 64; off <<= 1)
-#pragma unroll
-                            for (int k = 0; k < 16; ++k) v16[k] += __shfl_xor(v16[k], off, 64);
-                        if (lane < CH) {
-#pragma unroll
-                            for (int k = 0; k < 16; ++k) red[(wave * CH + lane) * 16 + k] = v16[k];
-                        }
-                    }
-                    __syncthreads();
-                    if (tid < CH * 16) {
-                        float a = 0.f;
-                        if (s2 < nslots) a = (red[tid] + red[CH * 16 + tid]) + (red[2 * CH * 16 + tid] + red[3 * CH * 16 + tid]);
-                        const int cg = tid >> 4, k = tid & 15;
-                        const int c = n0 + cg * 8 + (k & 7);
-                        if (c < Cout) out[((size_t)s2 * Cout + c) * 2 + (k >> 3)] = a;
-                    }
-                    __syncthreads();
                 }
             }
         }
@@ -407,6 +390,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_conv3x3_dma(const 
 #endif
         if (!have_next) break;
         cur = nxt;
+#pragma unroll
+        for (int k = 0; k < S2_MAXP; ++k) so_cur[k] = so_nxt[k];
     }
 #if FNET_CONV_STAMPS
     if (tid == 0 && stamps) {
@@ -418,14 +403,9 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_conv3x3_dma(const 
     }
 #endif
 #undef STAMP
-#undef FNET_WLOAD
-#undef FNET_WSTORE
-#undef FNET_WL1
-#undef FNET_WS1
 }
 
 // ------------------------------------------------------------------------------------------- weight gradient
-constexpr int KP = 128;        // pixels per staged chunk
 constexpr int PANEL_ROW = 64;  // bytes: 32 bf16 channels
 
 // transposed fragment: lane (r = lane&31, h = lane>>5) gets M[k0 + 8h + j][c = r], j = 0..7, from a [rows][32] bf16 panel
@@ -444,77 +424,6 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* panel, int k0, in
     return __builtin_bit_cast(bf16x8, v);
 }
 
-// stage `rows` pixels starting at global pixel g0 into NP panels of [rows][32] (channels c_base .. c_base + 32*NP), zero outside
-template <int NP>
-__device__ __forceinline__ void stage_panels(unsigned char* lds, int rows, const bf16_t* __restrict__ src, long long g0, int Npix,
-                                             int ldc, int coff, int c_base, int C, int tid) {
-    const int pieces = rows * NP * 4;  // 16-B pieces: 4 per 32-channel row
-    for (int p = tid; p < pieces; p += kThreads) {
-        const int piece = p & 3, rp = p >> 2;
-        const int row = rp % rows, panel = rp / rows;
-        const int c = c_base + panel * 32 + piece * 8;
-        const long long g = g0 + row;
-        uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (g >= 0 && g < Npix && c < C) v = *reinterpret_cast<const uint4*>(src + (size_t)g * ldc + coff + c);
-        *reinterpret_cast<uint4*>(lds + ((size_t)panel * rows + row) * PANEL_ROW + piece * 16) = v;
-    }
-}
-
-template <int NCO, int NCI>
-__global__ __launch_bounds__(256) void k_wgrad_mfma(const bf16_t* __restrict__ src, const bf16_t* __restrict__ dout,
-                                                    float* __restrict__ dWk, int Npix, int Wp, int Cin, int ldc_in, int coff_in,
-                                                    int Cout, int ldc_do, int coff_do, int Cin_w, int chunks_per_block) {
-    constexpr int KS = 4 / (NCO * NCI);  // waves that share one (co,ci) panel pair and split the k-steps
-    constexpr int SROWS = KP + 2;
-    __shared__ __attribute__((aligned(16))) unsigned char lds_do[NCO * KP * PANEL_ROW];
-    __shared__ __attribute__((aligned(16))) unsigned char lds_src[NCI * SROWS * PANEL_ROW];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int cop = wave % NCO, cip = (wave / NCO) % NCI, ksl = wave / (NCO * NCI);
-    const int co_base = blockIdx.y * (32 * NCO), ci_base = blockIdx.z * (32 * NCI);
-    const int r = lane & 31, h = lane >> 5;
-
-    f32x16 acc[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
-
-    const long long fbeg = (long long)blockIdx.x * chunks_per_block * KP;
-    for (int ch = 0; ch < chunks_per_block; ++ch) {
-        const long long f0 = fbeg + (long long)ch * KP;
-        if (f0 >= Npix) break;  // uniform across the block
-        stage_panels<NCO>(lds_do, KP, dout, f0, Npix, ldc_do, coff_do, co_base, Cout, tid);
-#pragma unroll
-        for (int ty = 0; ty < 3; ++ty) {
-            stage_panels<NCI>(lds_src, SROWS, src, f0 + (long long)(ty - 1) * Wp - 1, Npix, ldc_in, coff_in, ci_base, Cin, tid);
-            __syncthreads();
-            const unsigned char* pa = lds_do + (size_t)cop * KP * PANEL_ROW;
-            const unsigned char* pb = lds_src + (size_t)cip * SROWS * PANEL_ROW;
-            for (int ks = ksl; ks < KP / 16; ks += KS) {
-                const bf16x8 a = tr_frag(pa, ks * 16, lane);
-#pragma unroll
-                for (int tx = 0; tx < 3; ++tx) {
-                    const bf16x8 b = tr_frag(pb, ks * 16 + tx, lane);
-                    acc[ty * 3 + tx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[ty * 3 + tx], 0, 0, 0);
-                }
-            }
-            __syncthreads();
-        }
-    }
-    // D[row = co][col = ci]; lanes run along ci -> 128-B atomic segments
-    const int ci = ci_base + cip * 32 + r;
-    if (ci < Cin) {
-#pragma unroll
-        for (int t = 0; t < 9; ++t)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int co = co_base + cop * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                if (co < Cout) atomicAdd(dWk + ((size_t)t * Cout + co) * Cin_w + ci, acc[t][i]);
-            }
-    }
-}
-
 // ---- weight gradient, LDS-DMA double-buffered, 2-D pixel chunks, slab reduction ------------------------------------
 // K axis = interior pixels only (the ring of dout is zero by construction of every producer: INACT_BWD_APPLY, FOLD_SUM,
 // ZERO_INSERT), walked in chunks of 64 pixels shaped CH x CW (2 x 32 or 4 x 16) so that the source halo is
@@ -526,28 +435,33 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma(const bf16_t* __restrict__ s
 // atomic rate: ~140 MB of adds per launch at 1.3 TB/s was a third of the kernel.)
 constexpr int WG_PX = 64;                 // pixels per chunk
 constexpr int WG_SROWS = 144;             // source rows staged per panel (>= (CH+2)*(CW+2))
+constexpr int WG_SROWS_S2 = 112;          // ... in the 2x2 (stride-2) form (>= (CH+1)*(CW+1))
 constexpr int WG_PART = 9 * 32 * 32;      // floats per wave partial
 
 // one stage of DMA for chunk c into LDS buffer `buf` (see k_wgrad_dma)
-template <int NCO, int NCI, int PPW>
+template <int NCO, int NCI, int PPW, bool S2>
 __device__ __forceinline__ void wg_issue(unsigned char* smem, const bf16_t* __restrict__ src, const bf16_t* __restrict__ dout, int c, int buf,
                                          int wave, int H, int W, int ldc_in, int ldc_do, int log2cw, int cpi, int ncx,
                                          const int (&p_off)[PPW], const int (&p_lds)[PPW], const int (&p_cyx)[PPW]) {
+    constexpr int SROWS = S2 ? WG_SROWS_S2 : WG_SROWS;
     constexpr int DB = NCO * WG_PX * PANEL_ROW;
-    constexpr int SB = NCI * WG_SROWS * PANEL_ROW;
+    constexpr int SB = NCI * SROWS * PANEL_ROW;
     constexpr int STAGE = DB + SB;
     constexpr int NPD = NCO * (WG_PX / 16);
-    constexpr int NP = NPD + NCI * (WG_SROWS / 16);
+    constexpr int NP = NPD + NCI * (SROWS / 16);
     const int Hp = H + 2, Wp = W + 2;
     const int CW = 1 << log2cw, CH = WG_PX >> log2cw;
     const int n = c / cpi, rem = c - n * cpi;
     const int cyi = rem / ncx, cxi = rem - cyi * ncx;
     const int y0 = 1 + cyi * CH, x0 = 1 + cxi * CW;   // padded coordinates of the chunk origin
     const size_t img = (size_t)n * Hp * Wp;
+    // S2: the source is the full-resolution P-tensor ((2H+2) x (2W+2)) read as its space-to-depth view (see k_conv3x3_dma, MODE 1)
+    const int Hps = S2 ? 2 * H + 2 : Hp, Wps = S2 ? 2 * W + 2 : Wp;
+    const size_t simg = (size_t)n * Hps * Wps;
     const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc((void*)(dout + img * ldc_do), 0, Hp * Wp * ldc_do * 2, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rss = __builtin_amdgcn_make_buffer_rsrc((void*)(src + img * ldc_in), 0, Hp * Wp * ldc_in * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rss = __builtin_amdgcn_make_buffer_rsrc((void*)(src + simg * ldc_in), 0, Hps * Wps * ldc_in * 2, 0x00020000);
     const int dbase = (y0 * Wp + x0) * ldc_do * 2;
-    const int sbase = ((y0 - 1) * Wp + x0 - 1) * ldc_in * 2;
+    const int sbase = S2 ? (2 * (y0 - 1) * Wps + 2 * (x0 - 1)) * ldc_in * 2 : ((y0 - 1) * Wp + x0 - 1) * ldc_in * 2;
     unsigned char* base = smem + buf * STAGE;
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
@@ -563,18 +477,19 @@ __device__ __forceinline__ void wg_issue(unsigned char* smem, const bf16_t* __re
     }
 }
 
-template <int NCO, int NCI>
+template <int NCO, int NCI, bool S2>
 __global__ __launch_bounds__(256, 2) void k_wgrad_dma(const bf16_t* __restrict__ src, const bf16_t* __restrict__ dout,
                                                       float* __restrict__ slab, int B, int H, int W, int ldc_in, int coff_in,
                                                       int ldc_do, int coff_do, int log2cw, int chunks_per_block, int nchunks,
-                                                      int nparts, int n_ci_tiles) {
+                                                      int nparts, int n_ci_tiles, int Cs) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int KS = 4 / (NCO * NCI);       // waves that share one (co,ci) panel pair and split the k-steps
+    constexpr int SROWS = S2 ? WG_SROWS_S2 : WG_SROWS;
     constexpr int DB = NCO * WG_PX * PANEL_ROW;      // dout bytes per stage
-    constexpr int SB = NCI * WG_SROWS * PANEL_ROW;   // source bytes per stage
+    constexpr int SB = NCI * SROWS * PANEL_ROW;      // source bytes per stage
     constexpr int STAGE = DB + SB;
     constexpr int NPD = NCO * (WG_PX / 16);          // DMA pieces (16 rows x 64 B) per stage: dout
-    constexpr int NPSP = WG_SROWS / 16;              // ... per source panel
+    constexpr int NPSP = SROWS / 16;              // ... per source panel
     constexpr int NP = NPD + NCI * NPSP;
     constexpr int PPW = (NP + 3) / 4;                // pieces per wave
     const int tid = threadIdx.x, lane = tid & 63;
@@ -582,8 +497,9 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_dma(const bf16_t* __restrict__
     const int cop = wave % NCO, cip = (wave / NCO) % NCI, ksl = wave / (NCO * NCI);
     const int co_tile = blockIdx.y, ci_tile = blockIdx.z;
     const int co_base = co_tile * (32 * NCO), ci_base = ci_tile * (32 * NCI);
-    const int Wp = W + 2;
-    const int CW = 1 << log2cw, CH = WG_PX >> log2cw, SW = CW + 2;
+    constexpr int NTAPS = S2 ? 4 : 9, TW = S2 ? 2 : 3;
+    const int Wp = W + 2, Wps = 2 * W + 2;
+    const int CW = 1 << log2cw, CH = WG_PX >> log2cw, SW = CW + (S2 ? 1 : 2);
     const int ncx = (W + CW - 1) >> log2cw, ncy = (H + CH - 1) / CH;
     const int cpi = ncx * ncy;                       // chunks per image
 
@@ -605,28 +521,34 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_dma(const bf16_t* __restrict__
             const int panel = ps / NPSP, j = ps % NPSP;
             const int row = 16 * j + row16;
             const int iy = row / SW, ix = row - iy * SW;
-            p_off[i] = ((iy * Wp + ix) * ldc_in + coff_in + ci_base + panel * 32 + piece16) * 2;
-            p_lds[i] = DB + panel * (WG_SROWS * PANEL_ROW) + j * 1024;
+            if (S2) {
+                // 32-channel panel of the 4C axis = channels c0 .. c0+31 of phase (py, px): Cs is a multiple of 32
+                const int cb = ci_base + panel * 32, ph = cb / Cs, c0 = cb - ph * Cs;
+                p_off[i] = (((2 * iy + (ph >> 1)) * Wps + 2 * ix + (ph & 1)) * ldc_in + coff_in + c0 + piece16) * 2;
+            } else {
+                p_off[i] = ((iy * Wp + ix) * ldc_in + coff_in + ci_base + panel * 32 + piece16) * 2;
+            }
+            p_lds[i] = DB + panel * (SROWS * PANEL_ROW) + j * 1024;
             p_cyx[i] = 0;
         }
     }
 
 
-    f32x16 acc[9];
+    f32x16 acc[NTAPS];
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < NTAPS; ++t)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
     const int c_begin = blockIdx.x * chunks_per_block;
     const int c_end = min(nchunks, c_begin + chunks_per_block);
-    if (c_begin < c_end) wg_issue<NCO, NCI, PPW>(smem, src, dout, c_begin, 0, wave, H, W, ldc_in, ldc_do, log2cw, cpi, ncx, p_off, p_lds, p_cyx);
+    if (c_begin < c_end) wg_issue<NCO, NCI, PPW, S2>(smem, src, dout, c_begin, 0, wave, H, W, ldc_in, ldc_do, log2cw, cpi, ncx, p_off, p_lds, p_cyx);
     for (int c = c_begin; c < c_end; ++c) {
         __syncthreads();
         const int cur = (c - c_begin) & 1;
-        if (c + 1 < c_end) wg_issue<NCO, NCI, PPW>(smem, src, dout, c + 1, cur ^ 1, wave, H, W, ldc_in, ldc_do, log2cw, cpi, ncx, p_off, p_lds, p_cyx);
+        if (c + 1 < c_end) wg_issue<NCO, NCI, PPW, S2>(smem, src, dout, c + 1, cur ^ 1, wave, H, W, ldc_in, ldc_do, log2cw, cpi, ncx, p_off, p_lds, p_cyx);
         const unsigned char* pa = smem + cur * STAGE + cop * (WG_PX * PANEL_ROW);
-        const unsigned char* pb = smem + cur * STAGE + DB + cip * (WG_SROWS * PANEL_ROW);
+        const unsigned char* pb = smem + cur * STAGE + DB + cip * (SROWS * PANEL_ROW);
 #pragma unroll
         for (int kk = 0; kk < (WG_PX / 16) / KS; ++kk) {
             const int ks = ksl + kk * KS;
@@ -634,11 +556,11 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_dma(const bf16_t* __restrict__
             const int cy = row0 >> log2cw, cx0 = row0 & (CW - 1);
             const bf16x8 a = tr_frag(pa, row0, lane);
 #pragma unroll
-            for (int ty = 0; ty < 3; ++ty)
+            for (int ty = 0; ty < TW; ++ty)
 #pragma unroll
-                for (int tx = 0; tx < 3; ++tx) {
+                for (int tx = 0; tx < TW; ++tx) {
                     const bf16x8 b = tr_frag(pb, (cy + ty) * SW + cx0 + tx, lane);
-                    acc[ty * 3 + tx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[ty * 3 + tx], 0, 0, 0);
+                    acc[ty * TW + tx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[ty * TW + tx], 0, 0, 0);
                 }
         }
     }
@@ -651,14 +573,14 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_dma(const bf16_t* __restrict__
             __syncthreads();                  // stage buffers (j = 1) / the previous round's image are no longer read
             if (ksl == j) {
 #pragma unroll
-                for (int t = 0; t < 9; ++t)
+                for (int t = 0; t < NTAPS; ++t)
 #pragma unroll
                     for (int i = 0; i < 16; ++i) xch[(t * 16 + i) * 64 + lane] = acc[t][i];
             }
             __syncthreads();
             if (ksl == 0) {
 #pragma unroll
-                for (int t = 0; t < 9; ++t)
+                for (int t = 0; t < NTAPS; ++t)
 #pragma unroll
                     for (int i = 0; i < 16; ++i) acc[t][i] += xch[(t * 16 + i) * 64 + lane];
             }
@@ -668,9 +590,9 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_dma(const bf16_t* __restrict__
     // D[row = co][col = ci]: partial[t][co][ci], lanes run along ci (two 128-B segments per store instruction)
     const int r = lane & 31, h = lane >> 5;
     const size_t pair = (size_t)(co_tile * NCO + cop) * (n_ci_tiles * NCI) + (ci_tile * NCI + cip);
-    float* part = slab + (pair * nparts + (size_t)blockIdx.x) * WG_PART;
+    float* part = slab + (pair * nparts + (size_t)blockIdx.x) * WG_PART;      // (the 2x2 form uses the first 4 of the 9 tap images)
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < NTAPS; ++t)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int co = (i & 3) + 8 * (i >> 2) + 4 * h;
@@ -681,9 +603,9 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_dma(const bf16_t* __restrict__
 // dWk[t][co][ci] += sum over partials of the (co/32, ci/32) pair.  grid = (elements / 256, partial groups); one float atomic
 // per (element, group) -- a few MB per launch.
 __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ slab, float* __restrict__ dWk, int Cout, int Cin, int Cin_w,
-                                                      int nparts, int parts_per_group, int n_ci_panels) {
+                                                      int nparts, int parts_per_group, int n_ci_panels, int ntaps) {
     const int e = blockIdx.x * kThreads + threadIdx.x;
-    if (e >= 9 * Cout * Cin) return;
+    if (e >= ntaps * Cout * Cin) return;
     const int ci = e % Cin, rest = e / Cin, co = rest % Cout, t = rest / Cout;
     const size_t pair = (size_t)(co >> 5) * n_ci_panels + (ci >> 5);
     const int s0 = blockIdx.y * parts_per_group, s1 = min(nparts, s0 + parts_per_group);
@@ -713,20 +635,31 @@ int set_lds_limit(K kernel, size_t bytes) {
 
 }  // namespace
 
+// CONV3X3 (impl = MFMA)  i: 9 mode (0 = 3x3; 1 = stride-2 forward, 2 = stride-2 data gradient: see the kernel), modes 1 / 2: 10 = h (rows of
+// the half-resolution image; Npix and Wp describe that half-resolution padded space), 11 = C (channels per phase: Cin = 4C in mode 1 and
+// ldc_in / coff_in address the full-resolution source; Cout = 4C in mode 2 and ldc_out / coff_out address the full-resolution
+// destination).  p[4] = cycle-stamp scratch of the diagnostic build, else unused.
 int fnet_conv3x3_mfma(const FnetOp& op, hipStream_t st) {
-    const int Npix = op.i[0], Wp = op.i[1], Cin = op.i[2], Cout = op.i[5];
-    FNET_CHECK_ARG(op.dtype == FNET_BF16);
+    const int Npix = op.i[0], Wp = op.i[1], Cin = op.i[2], Cout = op.i[5], mode = op.i[9];
+    FNET_CHECK_ARG(op.dtype == FNET_BF16 && mode >= 0 && mode <= 2);
     FNET_CHECK_ARG(Npix > 0 && Wp >= 3 && Cin % 8 == 0 && Cin > 0 && Cout % 8 == 0 && Cout > 0);
     FNET_CHECK_ARG(op.i[3] % 8 == 0 && op.i[4] % 8 == 0 && op.i[6] % 8 == 0 && op.i[7] % 8 == 0);
-    FNET_CHECK_ARG(op.i[4] + Cin <= op.i[3] && op.i[7] + Cout <= op.i[6]);
     FNET_CHECK_ARG(op.p[0] && op.p[1] && op.p[3] && (op.p[0] % 16) == 0 && (op.p[1] % 16) == 0 && (op.p[3] % 16) == 0);
-    // optional fused InstanceNorm partial sums: p[4] = scratch (i[9] floats), i[10] = H (W = Wp - 2)
-    float* stats_part = (float*)op.p[4];
-    const int H = op.i[10], W = Wp - 2;
-    if (stats_part) {
-        FNET_CHECK_ARG(H >= 1 && W >= 1 && (H + 2) * Wp >= TM && Npix % ((H + 2) * Wp) == 0);
-        FNET_CHECK_ARG((long long)((Npix + TM - 1) / TM) * 4 * Cout <= (long long)op.i[9]);
+    ConvS2 g2 = {0, 0, 1, 0.f, 0.f, 0.f};
+    if (mode) {
+        const int hh = op.i[10], Cs = op.i[11], wh = Wp - 2;
+        FNET_CHECK_ARG(hh >= 1 && wh >= 1 && Cs >= 16 && Cs % 16 == 0 && Npix % ((hh + 2) * Wp) == 0 && Npix < (1 << 24));
+        const long long full = (long long)(Npix / ((hh + 2) * Wp)) * (2 * hh + 2) * (2 * wh + 2);   // pixels of the full-resolution P-tensor
+        if (mode == 1) {
+            FNET_CHECK_ARG(Cin == 4 * Cs && op.i[4] + Cs <= op.i[3] && op.i[7] + Cout <= op.i[6] && full * op.i[3] * 2 < (1ll << 31));
+        } else {
+            FNET_CHECK_ARG(Cout == 4 * Cs && op.i[4] + Cin <= op.i[3] && op.i[7] + Cs <= op.i[6] && full * op.i[6] < (1ll << 31));
+        }
+        g2 = {hh, Cs, (hh + 2) * Wp, 1.f / (float)((hh + 2) * Wp), 1.f / (float)Wp, 1.f / (float)Cs};
+    } else {
+        FNET_CHECK_ARG(op.i[4] + Cin <= op.i[3] && op.i[7] + Cout <= op.i[6]);
     }
+    float* stamps = FNET_CONV_STAMPS ? (float*)op.p[4] : nullptr;
     int cus = 256;
     {
         int dev = 0;
@@ -734,36 +667,41 @@ int fnet_conv3x3_mfma(const FnetOp& op, hipStream_t st) {
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
             cus = prop.multiProcessorCount;
     }
+    const int ntaps = mode ? 4 : 9;
+    const int halo = mode ? Wp + 1 : 2 * Wp + 2;   // pixels of the input run beyond the tile
     // Tile shape.  Small: 256 px x {32,64} couts, 4 waves, two blocks per CU.  Big: 512 px x {64,128} couts, 8 waves, one block
     // per CU: 1.6-2.3x fewer staged bytes per FLOP, taken when the layer has enough big tiles to keep every CU busy for at
     // least ~3 rounds (a partial last round of big tiles costs more than it saves on the small layers).
     // FNET_CONV_TILE=small|big forces one shape (tuning / tools/conv_bench.py).
     static const int forced = [] { const char* e = getenv("FNET_CONV_TILE"); return !e ? 0 : (e[0] == 's' ? 1 : (e[0] == 'b' ? 2 : 0)); }();
     bool big = false;
-    if ((FNET_CONV_STAMPS || !stats_part) && Cout > 32) {
+    if (Cout > 32) {
         const int tn_b = Cout > 64 ? 128 : 64;
         const long long items_b = (long long)((Npix + 511) / 512) * ((Cout + tn_b - 1) / tn_b);
         big = items_b >= 3ll * cus;
         if (forced) big = forced == 2;
-        // wide images: the big tile's two stage buffers (input run of 512 + 2Wp + 2 pixels) must fit the CU's 160 KB of LDS
-        const size_t rin_b = (size_t)(512 + 2 * Wp + 2 + 31) / 32 * 32;
-        size_t buf_b = rin_b * 32 + (size_t)9 * tn_b * 32;
+        if (mode == 1 && tn_b == 128) big = false;     // (that variant would spill: 8 gather offsets on top of 256 accumulator registers)
+        // wide images: the big tile's two stage buffers (input run of 512 + halo pixels) must fit the CU's 160 KB of LDS
+        const size_t rin_b = (size_t)(512 + halo + 31) / 32 * 32;
+        size_t buf_b = rin_b * 32 + (size_t)ntaps * tn_b * 32;
         const size_t out_b = (size_t)512 * 64 * 2 + 2048;
         if (buf_b < out_b) buf_b = out_b;
         if (2 * buf_b > 160 * 1024) big = false;
     }
     const int tm = big ? 512 : TM;
     const int TN = big ? (Cout > 64 ? 128 : 64) : (Cout > 32 ? 64 : 32);
-    const int rinp = (tm + 2 * Wp + 2 + 31) / 32 * 32;
-    // one stage buffer: weights + input run, and big enough for one output slice (+ 2 KB of statistics scratch)
-    size_t bufsz = (size_t)rinp * 32 + (size_t)9 * TN * 32;
+    const int rinp = (tm + halo + 31) / 32 * 32;
+    // one stage buffer: weights + input run, and big enough for one output slice
+    size_t bufsz = (size_t)rinp * 32 + (size_t)ntaps * TN * 32;
     const int tne = TN > 64 ? 64 : TN;
-    const size_t need = (size_t)tm * tne * 2 + 4 * (tne / 8) * 16 * 4;
+    const size_t need = (size_t)tm * tne * 2;
     if (bufsz < need) bufsz = need;
     const size_t lds = 2 * bufsz;
     FNET_CHECK_ARG(lds <= 160 * 1024);
     // the DMA window offsets are 32-bit
     FNET_CHECK_ARG((long long)(rinp + 2) * op.i[3] * 2 < (1ll << 30));
+    // mode 1 keeps a lane's gather offsets of the pieces its wave issues in S2_MAXP registers
+    FNET_CHECK_ARG(mode != 1 || (rinp / 32 + ntaps * TN / 32 + (big ? 8 : 4) - 1) / (big ? 8 : 4) <= S2_MAXP);
     const int n_mtiles = (Npix + tm - 1) / tm, n_ntiles = (Cout + TN - 1) / TN;
     const int n_items = 8 * ((n_mtiles + 7) / 8) * n_ntiles;
     // persistent grid: one (big) or two (small; LDS allows 2 at <= 80 KB each) blocks per CU, a multiple of 8 for the XCD mapping
@@ -775,98 +713,96 @@ int fnet_conv3x3_mfma(const FnetOp& op, hipStream_t st) {
     const bf16_t* Wk = (const bf16_t*)op.p[1];
     const float* bias = (const float*)op.p[2];
     bf16_t* dst = (bf16_t*)op.p[3];
-#define FNET_LAUNCH_CONV(TN_, NW_)                                                                                                   \
+#define FNET_LAUNCH_CONV(TN_, NW_, MODE_)                                                                                            \
     {                                                                                                                                \
-        int rc = set_lds_limit(k_conv3x3_dma<TN_, NW_>, lds);                                                                        \
+        int rc = set_lds_limit(k_conv3x3_dma<TN_, NW_, MODE_>, lds);                                                                 \
         if (rc) return rc;                                                                                                           \
-        hipLaunchKernelGGL((k_conv3x3_dma<TN_, NW_>), grid, dim3(NW_ * 64), lds, st, src, Wk, bias, dst, Npix, Wp, Cin, op.i[3],     \
-                           op.i[4], Cout, op.i[6], op.i[7], n_mtiles, n_ntiles, rinp, (int)bufsz, stats_part, H, W);                \
+        hipLaunchKernelGGL((k_conv3x3_dma<TN_, NW_, MODE_>), grid, dim3(NW_ * 64), lds, st, src, Wk, bias, dst, Npix, Wp, Cin,       \
+                           op.i[3], op.i[4], Cout, op.i[6], op.i[7], n_mtiles, n_ntiles, rinp, (int)bufsz, stamps, g2);              \
     }
-    if (big && TN == 128) FNET_LAUNCH_CONV(128, 8)
-    else if (big) FNET_LAUNCH_CONV(64, 8)
-    else if (TN == 64) FNET_LAUNCH_CONV(64, 4)
-    else FNET_LAUNCH_CONV(32, 4)
+#define FNET_LAUNCH_CONV_M(TN_, NW_)                                                                                                 \
+    {                                                                                                                                \
+        if (mode == 0) FNET_LAUNCH_CONV(TN_, NW_, 0)                                                                                 \
+        else if (mode == 1) FNET_LAUNCH_CONV(TN_, NW_, 1)                                                                            \
+        else FNET_LAUNCH_CONV(TN_, NW_, 2)                                                                                           \
+    }
+    if (big && TN == 128) {
+        if (mode == 2) FNET_LAUNCH_CONV(128, 8, 2) else FNET_LAUNCH_CONV(128, 8, 0)
+    }
+    else if (big) FNET_LAUNCH_CONV_M(64, 8)
+    else if (TN == 64) FNET_LAUNCH_CONV_M(64, 4)
+    else FNET_LAUNCH_CONV_M(32, 4)
+#undef FNET_LAUNCH_CONV_M
 #undef FNET_LAUNCH_CONV
     FNET_LAUNCH_CHECK();
     return FNET_OK;
 }
 
+// WGRAD (impl = MFMA)  i: 10 B, 11 H, 12 slab capacity in partials (36 KB each), 13 mode (0 = 3x3; 1 = the 2x2 space-to-depth form of a
+// stride-2 convolution: H and Wp describe the half-resolution dout, src is the full-resolution input of C = i[14] channels, Cin = 4C,
+// dWk = [4][Cout][Cin_w]).  p: 3 = partial slab.
 int fnet_wgrad_mfma(const FnetOp& op, hipStream_t st) {
     const int Npix = op.i[0], Wp = op.i[1], Cin = op.i[2], Cout = op.i[5], Cin_w = op.i[9];
-    FNET_CHECK_ARG(op.dtype == FNET_BF16);
+    const int B = op.i[10], H = op.i[11], W = Wp - 2, s2 = op.i[13], Cs = op.i[14];
+    FNET_CHECK_ARG(op.dtype == FNET_BF16 && op.p[3] && (s2 == 0 || s2 == 1));
     FNET_CHECK_ARG(Cin % 8 == 0 && Cout % 8 == 0 && op.i[3] % 8 == 0 && op.i[4] % 8 == 0 && op.i[6] % 8 == 0 && op.i[7] % 8 == 0);
     const int nco = Cout > 32 ? 2 : 1, nci = Cin > 32 ? 2 : 1;
-    const int tiles = ((Cout + 32 * nco - 1) / (32 * nco)) * ((Cin + 32 * nci - 1) / (32 * nci));
-    if (op.p[3]) {
-        // slab path: i[10] = B, i[11] = H, i[12] = slab capacity in partials (36 KB each)
-        const int B = op.i[10], H = op.i[11], W = Wp - 2;
-        FNET_CHECK_ARG(B > 0 && H >= 1 && W >= 1 && (long long)B * (H + 2) * Wp == Npix);
-        FNET_CHECK_ARG(op.i[4] + Cin <= op.i[3] && op.i[7] + Cout <= op.i[6]);
-        FNET_CHECK_ARG((long long)(H + 2) * Wp * op.i[3] * 2 < (1ll << 31) && (long long)(H + 2) * Wp * op.i[6] * 2 < (1ll << 31));
-        FNET_CHECK_ARG((op.p[0] % 16) == 0 && (op.p[1] % 16) == 0 && (op.p[3] % 16) == 0);
-        const int log2cw = W > 16 ? 5 : 4;
-        const int CW = 1 << log2cw, CH = WG_PX / CW;
-        const int nch = B * ((W + CW - 1) / CW) * ((H + CH - 1) / CH);
-        const int co_tiles = (Cout + 32 * nco - 1) / (32 * nco), ci_tiles = (Cin + 32 * nci - 1) / (32 * nci);
-        // one block per CU over the whole launch: the launch shares the chip with lane 0 (r2 sweep: 256 -> 38.10 ms, 512 -> 38.4 ms per K4 step)
-        static const int target_blocks = [] { const char* e = getenv("FNET_WG_BLOCKS"); return e ? atoi(e) : 256; }();
-        int splits = (target_blocks + tiles - 1) / tiles;
-        if (splits > nch) splits = nch;
-        int cpb = (nch + splits - 1) / splits;
-        splits = (nch + cpb - 1) / cpb;
-        const int nparts = splits;               // one partial per block and panel pair (the ks waves of a pair combine in LDS)
-        const long long need = (long long)co_tiles * nco * ci_tiles * nci * nparts;
-        FNET_CHECK_ARG(need <= op.i[12]);
-        const bf16_t* src = (const bf16_t*)op.p[0];
-        const bf16_t* dout = (const bf16_t*)op.p[1];
-        float* slab = (float*)op.p[3];
-        const dim3 grid(splits, co_tiles, ci_tiles);
-#define WGD_LAUNCH(A, B_)                                                                                                  \
-    {                                                                                                                     \
-        size_t lds = 2 * ((size_t)A * WG_PX * PANEL_ROW + (size_t)B_ * WG_SROWS * PANEL_ROW);                              \
-        if (A * B_ < 4 && lds < (size_t)A * B_ * WG_PART * 4) lds = (size_t)A * B_ * WG_PART * 4;                          \
-        int rc = set_lds_limit(k_wgrad_dma<A, B_>, lds);                                                                   \
-        if (rc) return rc;                                                                                                \
-        hipLaunchKernelGGL((k_wgrad_dma<A, B_>), grid, dim3(kThreads), lds, st, src, dout, slab, B, H, W, op.i[3], op.i[4], \
-                           op.i[6], op.i[7], log2cw, cpb, nch, nparts, ci_tiles);                                          \
+    const int ntaps = s2 ? 4 : 9;
+    FNET_CHECK_ARG(B > 0 && H >= 1 && W >= 1 && (long long)B * (H + 2) * Wp == Npix);
+    FNET_CHECK_ARG(op.i[7] + Cout <= op.i[6] && (long long)(H + 2) * Wp * op.i[6] * 2 < (1ll << 31));
+    if (s2) {
+        FNET_CHECK_ARG(Cs >= 32 && Cs % 32 == 0 && Cin == 4 * Cs && op.i[4] + Cs <= op.i[3]);
+        FNET_CHECK_ARG((long long)(2 * H + 2) * (2 * W + 2) * op.i[3] * 2 < (1ll << 31));
+    } else {
+        FNET_CHECK_ARG(op.i[4] + Cin <= op.i[3] && (long long)(H + 2) * Wp * op.i[3] * 2 < (1ll << 31));
     }
-        if (nco == 2 && nci == 2) WGD_LAUNCH(2, 2)
-        else if (nco == 2 && nci == 1) WGD_LAUNCH(2, 1)
-        else if (nco == 1 && nci == 2) WGD_LAUNCH(1, 2)
-        else WGD_LAUNCH(1, 1)
-#undef WGD_LAUNCH
-        const int elems = 9 * Cout * Cin;
-        const int eb = (elems + kThreads - 1) / kThreads;
-        static const int red_blocks = [] { const char* e = getenv("FNET_WG_RED_BLOCKS"); return e ? atoi(e) : 512; }();
-        int groups = (red_blocks + eb - 1) / eb;
-        if (groups > nparts) groups = nparts;
-        const int ppg = (nparts + groups - 1) / groups;
-        groups = (nparts + ppg - 1) / ppg;
-        hipLaunchKernelGGL(k_wgrad_reduce, dim3(eb, groups), dim3(kThreads), 0, st, (const float*)slab, (float*)op.p[2], Cout, Cin, Cin_w,
-                           nparts, ppg, ci_tiles * nci);
-        FNET_LAUNCH_CHECK();
-        return FNET_OK;
-    }
-    const int nchunks = (Npix + KP - 1) / KP;
-    // aim for ~4 blocks per CU over the whole launch, at least 2 chunks per block to amortise the atomics
-    int splits = (1024 + tiles - 1) / tiles;
-    if (splits > nchunks) splits = nchunks;
-    if (splits < 1) splits = 1;
-    int cpb = (nchunks + splits - 1) / splits;
-    if (cpb < 2 && nchunks >= 2) cpb = 2;
-    splits = (nchunks + cpb - 1) / cpb;
-    const dim3 grid(splits, (Cout + 32 * nco - 1) / (32 * nco), (Cin + 32 * nci - 1) / (32 * nci));
+    FNET_CHECK_ARG((op.p[0] % 16) == 0 && (op.p[1] % 16) == 0 && (op.p[3] % 16) == 0);
+    const int log2cw = W > 16 ? 5 : 4;
+    const int CW = 1 << log2cw, CH = WG_PX / CW;
+    const int nch = B * ((W + CW - 1) / CW) * ((H + CH - 1) / CH);
+    const int co_tiles = (Cout + 32 * nco - 1) / (32 * nco), ci_tiles = (Cin + 32 * nci - 1) / (32 * nci);
+    const int tiles = co_tiles * ci_tiles;
+    // one block per CU over the whole launch: the launch shares the chip with lane 0 (r2 sweep: 256 -> 38.10 ms, 512 -> 38.4 ms per K4 step)
+    static const int target_blocks = [] { const char* e = getenv("FNET_WG_BLOCKS"); return e ? atoi(e) : 256; }();
+    int splits = (target_blocks + tiles - 1) / tiles;
+    if (splits > nch) splits = nch;
+    int cpb = (nch + splits - 1) / splits;
+    splits = (nch + cpb - 1) / cpb;
+    const int nparts = splits;               // one partial per block and panel pair (the ks waves of a pair combine in LDS)
+    const long long need = (long long)co_tiles * nco * ci_tiles * nci * nparts;
+    FNET_CHECK_ARG(need <= op.i[12]);
     const bf16_t* src = (const bf16_t*)op.p[0];
     const bf16_t* dout = (const bf16_t*)op.p[1];
-    float* dWk = (float*)op.p[2];
-#define WG_LAUNCH(A, B)                                                                                                       \
-    hipLaunchKernelGGL((k_wgrad_mfma<A, B>), grid, dim3(kThreads), 0, st, src, dout, dWk, Npix, Wp, Cin, op.i[3], op.i[4], Cout, \
-                       op.i[6], op.i[7], Cin_w, cpb)
-    if (nco == 2 && nci == 2) WG_LAUNCH(2, 2);
-    else if (nco == 2 && nci == 1) WG_LAUNCH(2, 1);
-    else if (nco == 1 && nci == 2) WG_LAUNCH(1, 2);
-    else WG_LAUNCH(1, 1);
-#undef WG_LAUNCH
+    float* slab = (float*)op.p[3];
+    const dim3 grid(splits, co_tiles, ci_tiles);
+#define WGD_LAUNCH2(A, B_, S2_)                                                                                                       \
+    {                                                                                                                                \
+        size_t lds = 2 * ((size_t)A * WG_PX * PANEL_ROW + (size_t)B_ * (S2_ ? WG_SROWS_S2 : WG_SROWS) * PANEL_ROW);                   \
+        if (A * B_ < 4 && lds < (size_t)A * B_ * WG_PART * 4) lds = (size_t)A * B_ * WG_PART * 4;                                     \
+        int rc = set_lds_limit(k_wgrad_dma<A, B_, S2_>, lds);                                                                         \
+        if (rc) return rc;                                                                                                           \
+        hipLaunchKernelGGL((k_wgrad_dma<A, B_, S2_>), grid, dim3(kThreads), lds, st, src, dout, slab, B, H, W, op.i[3], op.i[4],      \
+                           op.i[6], op.i[7], log2cw, cpb, nch, nparts, ci_tiles, Cs);                                                \
+    }
+#define WGD_LAUNCH(A, B_)                                                                                                            \
+    {                                                                                                                                \
+        if (s2) WGD_LAUNCH2(A, B_, true) else WGD_LAUNCH2(A, B_, false)                                                              \
+    }
+    if (nco == 2 && nci == 2) WGD_LAUNCH(2, 2)
+    else if (nco == 2 && nci == 1) WGD_LAUNCH(2, 1)
+    else if (nco == 1 && nci == 2) WGD_LAUNCH(1, 2)
+    else WGD_LAUNCH(1, 1)
+#undef WGD_LAUNCH
+#undef WGD_LAUNCH2
+    const int elems = ntaps * Cout * Cin;
+    const int eb = (elems + kThreads - 1) / kThreads;
+    static const int red_blocks = [] { const char* e = getenv("FNET_WG_RED_BLOCKS"); return e ? atoi(e) : 512; }();
+    int groups = (red_blocks + eb - 1) / eb;
+    if (groups > nparts) groups = nparts;
+    const int ppg = (nparts + groups - 1) / groups;
+    groups = (nparts + ppg - 1) / ppg;
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3(eb, groups), dim3(kThreads), 0, st, (const float*)slab, (float*)op.p[2], Cout, Cin, Cin_w,
+                       nparts, ppg, ci_tiles * nci, ntaps);
     FNET_LAUNCH_CHECK();
     return FNET_OK;
 }

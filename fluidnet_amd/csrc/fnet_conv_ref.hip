@@ -87,12 +87,16 @@ int fnet_wgrad_ref(const FnetOp& op, hipStream_t st) {
     return FNET_OK;
 }
 
-// CONV3X3  i: 0 Npix,1 Wp,2 Cin,3 ldc_in,4 coff_in,5 Cout,6 ldc_out,7 coff_out,8 impl
+// CONV3X3  i: 0 Npix,1 Wp,2 Cin,3 ldc_in,4 coff_in,5 Cout,6 ldc_out,7 coff_out,8 impl,9 mode (MFMA: stride-2 forms, see fluidnet_ops.h)
 //          p: 0 src (P),1 Wk [9][Cout][Cin] (same element type as src),2 bias fp32|0,3 dst (P)
 int fnet_op_conv3x3(const FnetOp& op, hipStream_t st) {
     const int Npix = op.i[0], Wp = op.i[1], Cin = op.i[2], Cout = op.i[5];
     const int esz = op.dtype == FNET_BF16 ? 2 : 4;
     FNET_CHECK_ARG(Npix > 0 && Wp >= 3 && Cin > 0 && Cin % 8 == 0 && Cout > 0);
+    if (op.i[9] != 0) {                     // stride-2 forms (fnet_conv_mfma.hip): MFMA only, channel ranges checked there
+        FNET_CHECK_ARG(op.i[8] == FNET_CONV_MFMA && op.i[4] >= 0 && op.i[7] >= 0);
+        return fnet_conv3x3_mfma(op, st);
+    }
     FNET_CHECK_ARG(op.i[3] % 8 == 0 && op.i[4] % 8 == 0 && op.i[4] + Cin <= op.i[3]);
     FNET_CHECK_ARG(op.i[7] >= 0 && op.i[7] + Cout <= op.i[6]);
     FNET_CHECK_ARG(op.p[0] && op.p[1] && op.p[3] && op.p[0] % (8 * esz) == 0 && op.p[1] % (8 * esz) == 0);
@@ -107,8 +111,8 @@ int fnet_op_conv3x3(const FnetOp& op, hipStream_t st) {
 int fnet_op_wgrad(const FnetOp& op, hipStream_t st) {
     const int Npix = op.i[0], Wp = op.i[1], Cin = op.i[2], Cout = op.i[5], Cin_w = op.i[9];
     FNET_CHECK_ARG(Npix > 0 && Wp >= 3 && Cin > 0 && Cout > 0 && Cin_w >= Cin);
-    FNET_CHECK_ARG(op.i[4] >= 0 && op.i[4] + Cin <= op.i[3] && op.i[7] >= 0 && op.i[7] + Cout <= op.i[6]);
-    FNET_CHECK_ARG(op.p[0] && op.p[1] && op.p[2]);
+    FNET_CHECK_ARG(op.i[4] >= 0 && (op.i[13] != 0 || op.i[4] + Cin <= op.i[3]) && op.i[7] >= 0 && op.i[7] + Cout <= op.i[6]);
+    FNET_CHECK_ARG(op.p[0] && op.p[1] && op.p[2] && (op.i[13] == 0 || op.i[8] == FNET_CONV_MFMA));
     FNET_CHECK_ARG((long long)9 * Cout * Cin < (1ll << 31));
     if (op.i[8] == FNET_CONV_MFMA) return fnet_wgrad_mfma(op, st);
     FNET_CHECK_ARG(op.i[8] == FNET_CONV_REF);

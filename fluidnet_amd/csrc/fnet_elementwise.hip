@@ -257,26 +257,6 @@ __global__ __launch_bounds__(256) void k_in_finalize(const float2* part, float2*
     stats[i] = make_float2(mean, rsqrtf(var + eps));
 }
 
-// statistics whose partial sums were produced by the convolution epilogue (k_conv3x3_dma): part[tile][slot][C] float2,
-// tile = 256 flattened padded pixels, slot = image index relative to the tile's first image
-__global__ __launch_bounds__(256) void k_in_finalize_tiles(const float2* part, float2* stats, int B, int C, int HpWp, float inv_hw, float eps) {
-    const int i = blockIdx.x * kThreads + threadIdx.x;
-    if (i >= B * C) return;
-    const int n = i / C, c = i - n * C;
-    const long long p0 = (long long)n * HpWp, p1 = p0 + HpWp - 1;
-    const int t0 = (int)(p0 >> 8), t1 = (int)(p1 >> 8);
-    float sx = 0.f, sq = 0.f;
-#pragma unroll 8
-    for (int t = t0; t <= t1; ++t) {
-        const int first = (int)(((long long)t << 8) / HpWp);
-        const float2 v = part[((size_t)t * 2 + (n - first)) * C + c];
-        sx += v.x; sq += v.y;
-    }
-    const float mean = sx * inv_hw;
-    const float var = fmaxf(sq * inv_hw - mean * mean, 0.f);
-    stats[i] = make_float2(mean, rsqrtf(var + eps));
-}
-
 // ------------------------------------------------------------------ NORM_COMBINE (BatchNorm2d / GroupNorm on top of the per-(n,c) statistics)
 // IN_STATS leaves (mean, rstd) per (n, c).  With var = 1/rstd^2 - eps and E[x^2] = var + mean^2 those pool exactly: over n
 // (BatchNorm2d in training mode, unet.py:20-21; also updates the running statistics, momentum 0.1, unbiased variance) or over the
@@ -1127,19 +1107,10 @@ int fnet_op_pack_input(const FnetOp& op, hipStream_t st) {
     return FNET_OK;
 }
 
-// IN_STATS  i: 0 B,1 H,2 W,3 C,4 ldc,5 coff,6 scratch floats,7 mode (1 = scratch holds the conv epilogue's tile partials); f: 0 eps; p: 0 raw, 1 stats float2[B][C] = (mean, rstd), 2 scratch|0
+// IN_STATS  i: 0 B,1 H,2 W,3 C,4 ldc,5 coff,6 scratch floats; f: 0 eps; p: 0 raw, 1 stats float2[B][C] = (mean, rstd), 2 scratch|0
 int fnet_op_in_stats(const FnetOp& op, hipStream_t st) {
     const int B = op.i[0], H = op.i[1], W = op.i[2], C = op.i[3];
     FNET_CHECK_ARG(B > 0 && H > 0 && W > 0 && vec_ok((void*)op.p[0], op.i[4], op.i[5], C, op.dtype) && op.p[1]);
-    if (op.i[7] == 1) {
-        // the producing convolution already wrote per-tile partial sums into the scratch (fnet_conv3x3_mfma)
-        FNET_CHECK_ARG(op.p[2] && (H + 2) * (W + 2) >= 256);
-        FNET_CHECK_ARG(((long long)B * (H + 2) * (W + 2) + 255) / 256 * 4 * C <= (long long)op.i[6]);
-        hipLaunchKernelGGL(k_in_finalize_tiles, dim3((B * C + kThreads - 1) / kThreads), dim3(kThreads), 0, st, (const float2*)op.p[2],
-                           (float2*)op.p[1], B, C, (H + 2) * (W + 2), 1.f / (float)(H * W), op.f[0]);
-        FNET_LAUNCH_CHECK();
-        return FNET_OK;
-    }
     if (op.dtype == FNET_BF16 && cg_ok(C, B) && op.p[2]) {
         // one coalesced pass into per-block partials + ordered finalize (bf16 plans; p[2] = scratch of i[6] floats);
         // fp32 plans, or no scratch, keep the exact two-pass kernel below

@@ -61,6 +61,47 @@ __global__ __launch_bounds__(256) void k_unprep_wgrad_t2(const float* dWk, float
     dW[idx] = accumulate ? dW[idx] + v : v;
 }
 
+// Conv2d(C, Cout, 3, stride 2, padding 1) as the 2x2-tap convolution over the space-to-depth view of its input (k_conv3x3_dma, MODE 1 / 2):
+// K index k = (py, px, c) = ph * C + c of the 4C axis, tap t' = (dy, dx) carries W[co][c][ky = 2dy + py][kx = 2dx + px] (0 if ky or kx = 3).
+//   Wf[4][Cout_pad][4C], K-blocked [4C/16][4][Cout_pad][16];  Wd[(ty,tx)][k][co] = Wf[(1-ty, 1-tx)][co][k], K-blocked [Kd/16][4][4C][16]
+template <typename T>
+__global__ __launch_bounds__(256) void k_prep_weights_s2(const float* W, T* Wf, T* Wd, int Cout, int C, int Cout_pad, int Kd) {
+    const int idx = blockIdx.x * kThreads + threadIdx.x;
+    const int K = 4 * C;
+    const int nf = 4 * Cout_pad * K;
+    const int nd = Wd ? 4 * K * Kd : 0;
+    int t, co, k;
+    size_t o;
+    T* out;
+    if (idx < nf) {
+        k = idx % K; co = (idx / K) % Cout_pad; t = idx / (K * Cout_pad);
+        o = (((size_t)(k >> 4) * 4 + t) * Cout_pad + co) * 16 + (k & 15);
+        out = Wf;
+    } else if (idx < nf + nd) {
+        const int j = idx - nf;
+        co = j % Kd; k = (j / Kd) % K;
+        const int td = j / (Kd * K);
+        o = (((size_t)(co >> 4) * 4 + td) * K + k) * 16 + (co & 15);
+        t = 3 - td;                        // (1 - ty, 1 - tx)
+        out = Wd;
+    } else {
+        return;
+    }
+    const int ph = k / C, c = k - ph * C;
+    const int ky = 2 * (t >> 1) + (ph >> 1), kx = 2 * (t & 1) + (ph & 1);
+    st1<T>(out + o, (co < Cout && ky <= 2 && kx <= 2) ? W[((size_t)co * C + c) * 9 + ky * 3 + kx] : 0.f);
+}
+// dW[co][c][ky][kx] (+)= dWk[(ky>>1, kx>>1)][co][((ky&1), (kx&1), c)]
+__global__ __launch_bounds__(256) void k_unprep_wgrad_s2(const float* dWk, float* dW, int Cout, int C, int Cin_w, int accumulate, int Cout_pad) {
+    const int idx = blockIdx.x * kThreads + threadIdx.x;
+    if (idx >= Cout * C * 9) return;
+    const int tt = idx % 9, c = (idx / 9) % C, co = idx / (9 * C);
+    const int ky = tt / 3, kx = tt - ky * 3;
+    const int t = (ky >> 1) * 2 + (kx >> 1), ph = (ky & 1) * 2 + (kx & 1);
+    const float v = dWk[((size_t)t * Cout_pad + co) * Cin_w + ph * C + c];
+    dW[idx] = accumulate ? dW[idx] + v : v;
+}
+
 // dW[co][ci][t] (+)= dWk[t][co][ci]   (dWk rows = Cout_pad, row pitch Cin_w; padded rows / columns are dropped)
 __global__ __launch_bounds__(256) void k_unprep_wgrad(const float* dWk, float* dW, int Cout, int Cin, int Cin_w, int accumulate, int Cout_pad) {
     const int idx = blockIdx.x * kThreads + threadIdx.x;
@@ -106,7 +147,8 @@ __global__ __launch_bounds__(256) void k_adam(float* p, const float* g, float* m
 }  // namespace
 
 // PREP_WEIGHTS  i: 0 Cout,1 Cin,2 Cin_pad (K dim of Wf),3 Cout_d,4 blocked bits,5 Cout_pad (rows of Wf; 0 = Cout),6 Kd (K dim of Wd; 0 = Cout_pad),
-//                  7 kind (0 conv3x3, 1 transposed 2x2 stride 2: see k_prep_weights_t2)
+//                  7 kind (0 conv3x3, 1 transposed 2x2 stride 2: see k_prep_weights_t2, 2 conv3x3 stride 2 in its 2x2 space-to-depth form:
+//                    see k_prep_weights_s2; Cin = C, Cin_pad = Cout_d = 4C, both layouts K-blocked)
 //               p: 0 W fp32 OIHW,1 Wf [9][Cout_pad][Cin_pad],2 Wd [9][Cout_d][Kd]|0
 int fnet_op_prep_weights(const FnetOp& op, hipStream_t st) {
     const int Cout = op.i[0], Cin = op.i[1], Cin_pad = op.i[2], Cout_d = op.i[3], Cout_pad = op.i[5] ? op.i[5] : Cout;
@@ -121,6 +163,16 @@ int fnet_op_prep_weights(const FnetOp& op, hipStream_t st) {
         FNET_LAUNCH_CHECK();
         return FNET_OK;
     }
+    if (op.i[7] == 2) {
+        const int Kd = op.i[6] ? op.i[6] : Cout_pad;
+        FNET_CHECK_ARG(Cout > 0 && Cin >= 16 && Cin % 16 == 0 && Cin_pad == 4 * Cin && Cout_d == 4 * Cin && Cout_pad >= Cout && Kd >= Cout_pad);
+        FNET_CHECK_ARG(op.i[4] == 3 && Kd % 16 == 0 && op.p[0] && op.p[1]);
+        const int total = 4 * Cout_pad * 4 * Cin + (op.p[2] ? 4 * 4 * Cin * Kd : 0);
+        DISPATCH_T(op.dtype, hipLaunchKernelGGL(k_prep_weights_s2<T>, dim3((total + kThreads - 1) / kThreads), dim3(kThreads), 0, st,
+                                                (const float*)op.p[0], (T*)op.p[1], (T*)op.p[2], Cout, Cin, Cout_pad, Kd));
+        FNET_LAUNCH_CHECK();
+        return FNET_OK;
+    }
     FNET_CHECK_ARG(op.i[7] == 0);
     FNET_CHECK_ARG(Cout > 0 && Cin > 0 && Cin_pad >= Cin && Cout_pad >= Cout && op.p[0] && op.p[1] && (op.p[2] == 0 || Cout_d >= Cin));
     const int Kd = op.i[6] ? op.i[6] : Cout_pad;
@@ -132,7 +184,8 @@ int fnet_op_prep_weights(const FnetOp& op, hipStream_t st) {
     return FNET_OK;
 }
 
-// UNPREP_WGRAD  i: 0 Cout,1 Cin,2 Cin_w,3 accumulate,4 Cout_pad (0 = Cout),5 kind (0 conv3x3, 1 transposed 2x2); p: 0 dWk fp32 [9][Cout_pad][Cin_w],1 dW fp32 OIHW
+// UNPREP_WGRAD  i: 0 Cout,1 Cin,2 Cin_w,3 accumulate,4 Cout_pad (0 = Cout),5 kind (0 conv3x3, 1 transposed 2x2, 2 conv3x3 stride 2 in 2x2
+//                  form: dWk [4][Cout_pad][Cin_w >= 4 Cin]); p: 0 dWk fp32 [9][Cout_pad][Cin_w],1 dW fp32 OIHW
 int fnet_op_unprep_wgrad(const FnetOp& op, hipStream_t st) {
     const int Cout = op.i[0], Cin = op.i[1], Cin_w = op.i[2], Cout_pad = op.i[4] ? op.i[4] : Cout;
     FNET_CHECK_ARG(Cout > 0 && Cin > 0 && Cin_w >= Cin && Cout_pad >= Cout && op.p[0] && op.p[1]);
@@ -140,6 +193,14 @@ int fnet_op_unprep_wgrad(const FnetOp& op, hipStream_t st) {
         const int n = Cin * Cout * 4;
         hipLaunchKernelGGL(k_unprep_wgrad_t2, dim3((n + kThreads - 1) / kThreads), dim3(kThreads), 0, st, (const float*)op.p[0],
                            (float*)op.p[1], Cout, Cin, Cin_w, op.i[3]);
+        FNET_LAUNCH_CHECK();
+        return FNET_OK;
+    }
+    if (op.i[5] == 2) {
+        FNET_CHECK_ARG(Cin_w >= 4 * Cin);
+        const int n = 9 * Cout * Cin;
+        hipLaunchKernelGGL(k_unprep_wgrad_s2, dim3((n + kThreads - 1) / kThreads), dim3(kThreads), 0, st, (const float*)op.p[0],
+                           (float*)op.p[1], Cout, Cin, Cin_w, op.i[3], Cout_pad);
         FNET_LAUNCH_CHECK();
         return FNET_OK;
     }

@@ -7,6 +7,7 @@
 // fluidnet_amd/engine/plan.py:emit_forward (inference mode) record for record, so both hosts produce bit-identical states
 // (tests/test_gpu_native_rollout.py).
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -55,6 +56,13 @@ struct Rollout {
     PV pbuf(int h, int w, int C) { return PV{(bf16_t*)alloc((size_t)B * (h + 2) * (w + 2) * C * sizeof(bf16_t)), h, w, C, 0, C}; }
     float* pp(const std::string& name) { return params + off.at(name); }
     int impl_for(int cin, int cout) const { return (cin % 8 == 0 && cout % 8 == 0) ? FNET_CONV_MFMA : FNET_CONV_REF; }
+    // the stride-2 convolution of level L in its 2x2 space-to-depth form: the same rule as engine/plan.py _s2_native
+    bool s2_native(int L, int C) const {
+        static const bool on = [] { const char* e = getenv("FNET_S2"); return !e || (e[0] == '1' && !e[1]); }();
+        if (!on || cfg.downsample != 0 || C % 32) return false;
+        const long long h = H >> (L + 1), w = W >> (L + 1);
+        return (long long)B * (h + 2) * (w + 2) < (1ll << 24) && (long long)B * (2 * h + 2) * (2 * w + 2) * 2 * C * 2 < (1ll << 31) && w + 2 <= 500;
+    }
 };
 
 FnetOp mkop(int code) {
@@ -121,9 +129,24 @@ void build_params(Rollout& r) {
 // ---- op emitters (slots: include/fluidnet_ops.h)
 void e_conv(Rollout& r, const PV& src, const ConvEnt& ce, const float* bias, const PV& dst, int cin, int cout) {
     FnetOp o = mkop(FNET_OP_CONV3X3);
-    const int v[11] = {r.B * (src.H + 2) * (src.W + 2), src.W + 2, cin, src.ldc, src.coff, cout, dst.ldc, dst.coff, r.impl_for(cin, cout), 0, src.H};
+    const int v[10] = {r.B * (src.H + 2) * (src.W + 2), src.W + 2, cin, src.ldc, src.coff, cout, dst.ldc, dst.coff, r.impl_for(cin, cout), 0};
     memcpy(o.i, v, sizeof(v));
     o.p[0] = (uint64_t)src.buf; o.p[1] = (uint64_t)ce.Wf; o.p[2] = (uint64_t)bias; o.p[3] = (uint64_t)dst.buf;
+    r.frame.push_back(o);
+}
+// Conv2d(C, C, 3, stride 2) forward as the 2x2-tap convolution over the space-to-depth view of src (fnet_conv_mfma.hip, MODE 1)
+void e_conv_s2(Rollout& r, const PV& src, const ConvEnt& ce, const float* bias, const PV& dst) {
+    FnetOp o = mkop(FNET_OP_CONV3X3);
+    const int v[12] = {r.B * (dst.H + 2) * (dst.W + 2), dst.W + 2, 4 * src.C, src.ldc, src.coff, dst.C, dst.ldc, dst.coff, FNET_CONV_MFMA, 1, dst.H, src.C};
+    memcpy(o.i, v, sizeof(v));
+    o.p[0] = (uint64_t)src.buf; o.p[1] = (uint64_t)ce.Wf; o.p[2] = (uint64_t)bias; o.p[3] = (uint64_t)dst.buf;
+    r.frame.push_back(o);
+}
+void e_pad_ring(Rollout& r, const PV& x) {
+    FnetOp o = mkop(FNET_OP_PAD_RING);
+    const int v[7] = {r.B, x.H, x.W, x.C, x.ldc, x.coff, r.cfg.padding_mode};
+    memcpy(o.i, v, sizeof(v));
+    o.p[0] = (uint64_t)x.buf;
     r.frame.push_back(o);
 }
 int group_size(int groups, int ch) {          // channels per group of nn.GroupNorm as unet.py:24-28 builds it
@@ -139,7 +162,7 @@ PV unit(Rollout& r, const std::string& conv, const std::string& norm, const PV& 
     e_conv(r, xin, ce, nullptr, raw, ce.cin_pad, cout);
     if (r.cfg.norm != 1) {                      // eval-mode BatchNorm2d normalises with the running statistics alone
         FnetOp s = mkop(FNET_OP_IN_STATS);
-        const int v[8] = {r.B, raw.H, raw.W, raw.C, raw.ldc, raw.coff, (int)r.scratch_floats, 0};
+        const int v[7] = {r.B, raw.H, raw.W, raw.C, raw.ldc, raw.coff, (int)r.scratch_floats};
         memcpy(s.i, v, sizeof(v));
         s.f[0] = 1e-5f;
         s.p[0] = (uint64_t)raw.buf; s.p[1] = (uint64_t)st; s.p[2] = (uint64_t)r.stats_scratch;
@@ -180,6 +203,17 @@ void build_frame(Rollout& r) {
     for (auto& kv : r.convs) {
         ConvEnt& ce = kv.second;
         ce.cout_pad = cpad(ce.cout);
+        const std::string& name = kv.first;
+        if (name.size() > 5 && name.compare(name.size() - 5, 5, ".down") == 0 && r.s2_native(atoi(name.c_str() + 6), ce.cout)) {
+            ce.kf = 4 * ce.cin;
+            ce.Wf = (bf16_t*)r.alloc((size_t)4 * ce.cout_pad * ce.kf * sizeof(bf16_t));
+            FnetOp o = mkop(FNET_OP_PREP_WEIGHTS);
+            const int v[8] = {ce.cout, ce.cin, 4 * ce.cin, 4 * ce.cin, 3, ce.cout_pad, (ce.cout_pad + 15) / 16 * 16, 2};
+            memcpy(o.i, v, sizeof(v));
+            o.p[0] = (uint64_t)(r.params + ce.w_off); o.p[1] = (uint64_t)ce.Wf;
+            r.prep.push_back(o);
+            continue;
+        }
         const bool mfma = r.impl_for(ce.cin_pad, ce.cout_pad) == FNET_CONV_MFMA;
         ce.kf = mfma ? kpad(ce.cin_pad) : ce.cin_pad;
         ce.Wf = (bf16_t*)r.alloc((size_t)9 * ce.cout_pad * ce.kf * sizeof(bf16_t));
@@ -224,7 +258,10 @@ void build_frame(Rollout& r) {
             conv_block(r, d + ".block", x, C, &skip, false);
         }
         PV dn = r.pbuf(h / 2, w / 2, C);
-        if (c.downsample == 0) {
+        if (c.downsample == 0 && r.s2_native(L, C)) {
+            e_conv_s2(r, skip, r.convs.at(d + ".down"), r.pp(d + ".down.bias"), dn);
+            e_pad_ring(r, dn);
+        } else if (c.downsample == 0) {
             PV full = r.pbuf(h, w, C);
             e_conv(r, skip, r.convs.at(d + ".down"), nullptr, full, C, C);
             FnetOp o = mkop(FNET_OP_SUBSAMPLE_BIAS);

@@ -231,6 +231,11 @@ def wgrad_slab_parts(cfg) -> int:
             cot, cit = -(-co // (32 * nco)), -(-ci // (32 * nci))
             splits = -(-512 // (cot * cit))
             worst = max(worst, cot * nco * cit * nci * splits * (4 // (nco * nci)))
+            if s[2] == 3 and k.endswith(".down.weight") and cfg.downsample == "stride":
+                # the 2x2 space-to-depth form of the stride-2 convolution: K axis 4*ci
+                cit = -(-4 * ci // 64)
+                splits = -(-512 // (cot * cit))
+                worst = max(worst, cot * nco * cit * 2 * splits)
     return worst
 
 
@@ -294,8 +299,7 @@ class PlanBuilder:
         self.grads = self.new_buf("grads_flat", (off,), "f32", external=True)
         # per-block (sum, sumsq) partials of the one-pass InstanceNorm statistics: [B][chunks <= ceil(2048/B)][C][2]
         cmax = cfg.base_channels * 2 ** cfg.depth
-        # ... or, when the convolution epilogue produces them, [256-pixel tiles][2 image slots][C][2]
-        n_sc = max(B * ((2048 + B - 1) // B) * cmax * 2, ((B * (H + 2) * (W + 2) + 255) // 256) * 4 * cmax)
+        n_sc = B * ((2048 + B - 1) // B) * cmax * 2
         self.stats_scratch = self.new_buf("stats_scratch", (n_sc,), "f32")
         # per-wave partial results of the weight-gradient kernel (36 KB each); see wgrad_slab_parts()
         self.wgrad_slab = self.new_buf("wgrad_slab", (wgrad_slab_parts(cfg) * WG_PART,), "f32")
@@ -321,6 +325,15 @@ class PlanBuilder:
                 cop = cpad(co)
                 kf = kpad(cip) if self.impl_for(cip, cop) == rt.CONV_MFMA else cip
                 kd = kpad(cop) if self.impl_for(cop, cip) == rt.CONV_MFMA else cop
+                if self._s2_native(name, ci, co):
+                    # Conv2d(C, C, 3, stride 2) on the MFMA path: the 2x2-tap convolution over the space-to-depth view of its input
+                    # (fnet_conv_mfma.hip, MODE 1 / 2): K axis 4C, four taps
+                    self.convs[name] = dict(
+                        Cout=co, Cin=ci, Cin_pad=cip, Cout_d=cip, Cout_pad=cop, Kf=4 * cip, Kd=kd, s2=1,
+                        Wf=self.new_buf(f"Wf/{name}", (4, cop, 4 * cip), "T"),
+                        Wd=self.new_buf(f"Wd/{name}", (4, 4 * cip, kd), "T"),
+                        dWk=self.new_buf(f"dWk/{name}", (4, cop, 4 * cip), "f32"))
+                    continue
                 self.convs[name] = dict(
                     Cout=co, Cin=ci, Cin_pad=cip, Cout_d=cip, Cout_pad=cop, Kf=kf, Kd=kd,
                     Wf=self.new_buf(f"Wf/{name}", (9, cop, kf), "T"),
@@ -340,6 +353,17 @@ class PlanBuilder:
                     Wd=self.new_buf(f"Wd/{name}", (9, ci, kd), "T"),
                     dWk=self.new_buf(f"dWk/{name}", (9, rows, ci), "f32"))
         self._pack_dwk()
+
+    def _s2_native(self, name: str, ci: int, co: int) -> bool:
+        """Does the stride-2 convolution `name` (downs.L.down, unet.py:90-91) run in its 2x2 space-to-depth form?  bf16 MFMA plans, channel
+        counts the kernels' phase arithmetic covers, index ranges the kernels' 24-bit pixel / 31-bit byte offsets cover."""
+        if self.cfg.downsample != "stride" or not name.endswith(".down") or not name.startswith("downs.") or os.environ.get("FNET_S2", "1") != "1":
+            return False
+        if ci != co or ci % 32 or self.conv_impl == "ref" or self.dtype != rt.BF16:
+            return False
+        L = int(name.split(".")[1])
+        h, w = self.H >> (L + 1), self.W >> (L + 1)
+        return self.B * (h + 2) * (w + 2) < (1 << 24) and self.B * (2 * h + 2) * (2 * w + 2) * 2 * ci * 2 < (1 << 31) and w + 2 <= 500
 
     def _pack_dwk(self) -> None:
         """All weight-gradient accumulators live in one slab (each 32-B aligned): one ZERO per step instead of one per conv."""
@@ -480,26 +504,31 @@ class PlanBuilder:
         fl = 2.0 * self.B * H * W * 9 * c["Cin"] * c["Cout"]
         return fl / 4 if name.split("/")[0].endswith(".down") else fl
 
-    def fused_stats_ok(self, H: int, W: int, cin: int, cout: int) -> bool:
-        """The MFMA convolution can emit InstanceNorm partial sums from its epilogue when a 256-pixel tile touches at most
-        two images."""
-        if os.environ.get("FNET_FUSED_STATS", "0") != "1":      # measured: the epilogue costs as much as the separate one-pass kernel
-            return False
-        return self.impl_for(cin, cout) == rt.CONV_MFMA and (H + 2) * (W + 2) >= 256
-
-    def e_conv(self, ops, src: PV, wbuf: Buf, bias: Optional[Ref], dst: PV, cin: int, cout: int, tag="", stats: bool = False):
+    def e_conv(self, ops, src: PV, wbuf: Buf, bias: Optional[Ref], dst: PV, cin: int, cout: int, tag=""):
         npix = self.B * (src.H + 2) * (src.W + 2)
         assert (dst.H, dst.W) == (src.H, src.W) and src.C == cin and dst.C == cout, (tag, src.C, cin, dst.C, cout)
-        sc = self.stats_scratch
-        self.op(ops, "CONV3X3", [npix, src.W + 2, cin, src.ldc, src.coff, cout, dst.ldc, dst.coff, self.impl_for(cin, cout),
-                                 sc.numel if stats else 0, src.H],
-                p=[src.ref, Ref(wbuf), bias, dst.ref, Ref(sc) if stats else None], tag=tag)
+        self.op(ops, "CONV3X3", [npix, src.W + 2, cin, src.ldc, src.coff, cout, dst.ldc, dst.coff, self.impl_for(cin, cout), 0],
+                p=[src.ref, Ref(wbuf), bias, dst.ref, None], tag=tag)
         ops[-1].flops = self.conv_flops(tag, src.H, src.W)
+
+    def e_conv_s2(self, ops, src: PV, wbuf: Buf, bias: Optional[Ref], dst: PV, mode: int, tag=""):
+        """Stride-2 convolution in its 2x2 space-to-depth form.  mode 1 (forward): src = full-resolution input (C channels), dst = half
+        resolution; mode 2 (data gradient): src = half-resolution gradient, dst = full-resolution folded gradient (C channels)."""
+        full, half = (src, dst) if mode == 1 else (dst, src)
+        assert (full.H, full.W) == (2 * half.H, 2 * half.W), tag
+        C = full.C
+        npix = self.B * (half.H + 2) * (half.W + 2)
+        cin, cout = (4 * C, dst.C) if mode == 1 else (src.C, 4 * C)
+        self.op(ops, "CONV3X3", [npix, half.W + 2, cin, src.ldc, src.coff, cout, dst.ldc, dst.coff, rt.CONV_MFMA, mode, half.H, C],
+                p=[src.ref, Ref(wbuf), bias, dst.ref, None], tag=tag)
+        ops[-1].flops = self.conv_flops(tag, full.H, full.W)
 
     def e_wgrad(self, ops, src: PV, dout: PV, conv: str):
         c = self.convs[conv]
-        npix = self.B * (src.H + 2) * (src.W + 2)
+        s2 = c.get("s2", 0)
+        npix = self.B * (dout.H + 2) * (dout.W + 2)
         assert src.C == c["Cin_pad"] and dout.C == c["Cout_pad"], (conv, src.C, dout.C)
+        assert (src.H, src.W) == ((2 * dout.H, 2 * dout.W) if s2 else (dout.H, dout.W)), conv
         lane = self.wgrad_lane
         if lane:
             # all weight gradients share one lane: the partial slab and the dWk accumulators are touched in stream order there
@@ -508,14 +537,16 @@ class PlanBuilder:
             for b in (src.buf, dout.buf):
                 if b.name.startswith("tmp/"):
                     self._side_reads.add(id(b))
-        self.op(ops, "WGRAD", [npix, src.W + 2, src.C, src.ldc, src.coff, dout.C, dout.ldc, dout.coff,
-                               self.impl_for(src.C, dout.C), c["Cin_pad"], self.B, src.H, self.wgrad_slab.numel // WG_PART],
+        kc = 4 * src.C if s2 else src.C         # the GEMM's K-side channel count
+        self.op(ops, "WGRAD", [npix, dout.W + 2, kc, src.ldc, src.coff, dout.C, dout.ldc, dout.coff,
+                               self.impl_for(src.C, dout.C), 4 * c["Cin_pad"] if s2 else c["Cin_pad"], self.B, dout.H,
+                               self.wgrad_slab.numel // WG_PART, s2, src.C if s2 else 0],
                 p=[src.ref, dout.ref, Ref(c["dWk"]), Ref(self.wgrad_slab)], tag=conv, lane=lane)
         ops[-1].flops = self.conv_flops(conv, src.H, src.W)
 
-    def e_stats(self, ops, raw: PV, st: Buf, from_conv: bool = False):
+    def e_stats(self, ops, raw: PV, st: Buf):
         sc = self.stats_scratch
-        self.op(ops, "IN_STATS", [self.B, raw.H, raw.W, raw.C, raw.ldc, raw.coff, sc.numel, 1 if from_conv else 0], f=[1e-5],
+        self.op(ops, "IN_STATS", [self.B, raw.H, raw.W, raw.C, raw.ldc, raw.coff, sc.numel], f=[1e-5],
                 p=[raw.ref, Ref(st), Ref(sc)])
 
     def e_apply(self, ops, u: Unit):
@@ -537,10 +568,9 @@ class PlanBuilder:
         if out is None:
             out = PV(self.pbuf(f"{tape_name}/{conv}/act", H, W, cout), cout)
         u = Unit(conv, norm, xin, raw, st, out, res, drop_site, drop_p)
-        fused = self.fused_stats_ok(H, W, c["Cin_pad"], cout)
-        self.e_conv(ops, xin, c["Wf"], None, PV(raw, cout), c["Cin_pad"], cout, tag=conv, stats=fused)
+        self.e_conv(ops, xin, c["Wf"], None, PV(raw, cout), c["Cin_pad"], cout, tag=conv)
         if self.norm_kind != 3 and not self.no_norm:   # eval-mode BatchNorm2d normalises with the running statistics alone
-            self.e_stats(ops, PV(raw, cout), st, from_conv=fused)
+            self.e_stats(ops, PV(raw, cout), st)
         self.e_norm_combine(ops, norm, st, cout, H * W)
         self.e_apply(ops, u)
         return u
@@ -577,7 +607,12 @@ class PlanBuilder:
                 d["block"] = self._conv_block(ops, tn, f"downs.{L}.block", x, C, skip, False, site); site += 1
                 d["res"] = None
             dn = self.pbuf(f"{tn}/dn{L}", h // 2, w // 2, C)
-            if cfg.downsample == "stride":
+            if cfg.downsample == "stride" and self.convs[f"downs.{L}.down"].get("s2"):
+                name = f"downs.{L}.down"
+                self.e_conv_s2(ops, skip, self.convs[name]["Wf"], self.pref(name + ".bias"), PV(dn, C), 1, tag=name)
+                self.op(ops, "PAD_RING", [B, h // 2, w // 2, C, C, 0, self.pm], p=[Ref(dn)])
+                d["down"] = PlainConv(name, skip, PV(dn, C), 2)
+            elif cfg.downsample == "stride":
                 full = self.tmp(h, w, C)
                 name = f"downs.{L}.down"
                 self.e_conv(ops, skip, self.convs[name]["Wf"], None, PV(full, C), C, C, tag=name)
@@ -726,7 +761,8 @@ class PlanBuilder:
             self.release(s.pv.buf)
         # (r2: on the weight-gradient lane this launch and the loss sums cost 0.13 ms per step more than they hide; they stay on lane 0)
         self.op(ops, "BIAS_GRAD", [B, H, W, C, C, 0], p=[Ref(d), self.gref(pc.conv + ".bias")], tag=pc.conv)
-        if pc.stride == 2:
+        s2 = self.convs[pc.conv].get("s2", 0)
+        if pc.stride == 2 and not s2:
             full = self.tmp(2 * H, 2 * W, C)
             self.op(ops, "ZERO_INSERT", [B, H, W, C, C, 0, C, 0], p=[Ref(d), Ref(full)], tag=pc.conv)
             self.release(d)
@@ -736,7 +772,10 @@ class PlanBuilder:
         if need_dx:
             cin = pc.xin.C
             dpad = self.tmp(pc.xin.H, pc.xin.W, cin)
-            self.e_conv(ops, PV(d, C), self.convs[pc.conv]["Wd"], None, PV(dpad, cin), C, cin, tag=pc.conv + "/dgrad")
+            if s2:
+                self.e_conv_s2(ops, PV(d, C), self.convs[pc.conv]["Wd"], None, PV(dpad, cin), 2, tag=pc.conv + "/dgrad")
+            else:
+                self.e_conv(ops, PV(d, C), self.convs[pc.conv]["Wd"], None, PV(dpad, cin), C, cin, tag=pc.conv + "/dgrad")
             dx = GradSrc(PV(dpad, cin), 1)
         self.release(d)
         return dx
@@ -837,6 +876,10 @@ class PlanBuilder:
     # -------------------------------------------------------------------------------------------- weights / optimiser
     def emit_prep_weights(self, ops) -> None:
         for name, c in self.convs.items():
+            if c.get("s2"):
+                self.op(ops, "PREP_WEIGHTS", [c["Cout"], c["Cin"], 4 * c["Cin"], 4 * c["Cin"], 3, c["Cout_pad"], c["Kd"], 2],
+                        p=[self.pref(name + ".weight"), Ref(c["Wf"]), Ref(c["Wd"])], tag=name)
+                continue
             blocked = (1 if self.impl_for(c["Cin_pad"], c["Cout_pad"]) == rt.CONV_MFMA else 0) | \
                       (2 if self.impl_for(c["Cout_pad"], c["Cout_d"]) == rt.CONV_MFMA else 0)
             self.op(ops, "PREP_WEIGHTS", [c["Cout"], c["Cin"], c["Kf"], c["Cout_d"], blocked, c["Cout_pad"], c["Kd"], c.get("tr", 0)],
@@ -858,7 +901,8 @@ class PlanBuilder:
         for name, c in self.convs.items():
             if name in skip or (prefixes is not None and not name.startswith(tuple(prefixes))):
                 continue
-            self.op(ops, "UNPREP_WGRAD", [c["Cout"], c["Cin"], c["Cin_pad"], 0, c["Cout_pad"], c.get("tr", 0)],
+            self.op(ops, "UNPREP_WGRAD", [c["Cout"], c["Cin"], 4 * c["Cin_pad"] if c.get("s2") else c["Cin_pad"], 0, c["Cout_pad"],
+                                          2 if c.get("s2") else c.get("tr", 0)],
                     p=[Ref(c["dWk"]), self.gref(name + ".weight")], tag=name, lane=lane)
             done.append(name)
         return done

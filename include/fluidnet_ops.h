@@ -16,22 +16,26 @@
  * CONV3X3           <- nn.Conv2d(k=3, padding=1) forward, and its data gradient on flipped weights
  *                      (ml/models/unet.py:55, 59, 92, 218; autograd's conv backward-data)
  *   i: 0 Npix, 1 Wp, 2 Cin, 3 ldc_in, 4 coff_in, 5 Cout, 6 ldc_out, 7 coff_out, 8 impl (FNET_CONV_*),
- *      9 floats available at p[4], 10 H (needed only when p[4] != 0)
+ *      9 mode (MFMA only): 0 = 3x3; 1 / 2 = nn.Conv2d(C, Cout, 3, stride=2, padding=1) (ml/models/unet.py:90-91) forward / data gradient
+ *      as a 2x2-tap convolution over the space-to-depth view X'[Y][X][(py,px,c)] = Xpad[2Y+py][2X+px][c] of the full-resolution
+ *      input: Npix, Wp describe the HALF-resolution padded space, 10 = h (half-resolution rows), 11 = C;
+ *        mode 1: Cin = 4C, ldc_in / coff_in address the full-resolution source P, dst = half-resolution P (Cout channels);
+ *        mode 2: src = half-resolution gradient P (Cin = the conv's Cout, ring zero), Cout = 4C, ldc_out / coff_out address the
+ *                full-resolution destination P (C channels): every cell, ring included, is written once (a folded gradient);
+ *        weights [4][rows][K] K-blocked, PREP_WEIGHTS kind 2
  *   p: 0 src P, 1 weights (same element type as src): impl REF [9][Cout][Cin]; impl MFMA K-blocked
  *      [ceil(Cin/16)][9][Cout][16] as written by PREP_WEIGHTS (MFMA: Cin % 8 == 0 suffices -- the last K stage may
  *      overrun 8 channels into the next pixel against the zero-padded weights), 2 bias fp32|0, 3 dst P (every pixel incl.
- *      ring is written; the ring is then overwritten by APPLY / PAD_RING),
- *      4 |0 per-tile InstanceNorm partial sums float2[ceil(Npix/256)][4][Cout] (MFMA only; consumed
- *      by IN_STATS mode 1)
+ *      ring is written; the ring is then overwritten by APPLY / PAD_RING)
  * WGRAD             <- autograd's conv backward-weight
  *   i: 0 Npix, 1 Wp, 2 Cin, 3 ldc_in, 4 coff_in, 5 Cout, 6 ldc_do, 7 coff_do, 8 impl, 9 Cin_w (row
- *      length of dWk), 10 B, 11 H, 12 capacity of p[3] in partials of 9*32*32 floats
+ *      length of dWk), 10 B, 11 H, 12 capacity of p[3] in partials of 9*32*32 floats,
+ *      13 mode (MFMA only): 1 = the stride-2 convolution in its 2x2 space-to-depth form (CONV3X3 mode 1): Npix, Wp, H describe the
+ *      half-resolution dout, src is the full-resolution input of 14 = C channels, Cin = 4C, dWk = [4][Cout][Cin_w >= 4C]
  *   p: 0 src P (the conv's input), 1 dout P (gradient of the conv's output, ring = 0),
- *      2 dWk fp32 [9][Cout][Cin_w] (+=), 3 |0 partial slab (MFMA: per-wave partials + ordered
- *      reduce; without it the MFMA kernel falls back to float atomics)
+ *      2 dWk fp32 [9][Cout][Cin_w] (+=), 3 partial slab (MFMA: per-block partials + ordered reduce; REF: unused)
  * IN_STATS          <- InstanceNorm2d statistics (ml/models/unet.py:22-23, nn.InstanceNorm2d(affine=True))
- *   i: 0 B, 1 H, 2 W, 3 C, 4 ldc, 5 coff, 6 floats available at p[2], 7 mode (0 = read raw;
- *      1 = p[2] already holds CONV3X3's per-tile partials); f: 0 eps
+ *   i: 0 B, 1 H, 2 W, 3 C, 4 ldc, 5 coff, 6 floats available at p[2]; f: 0 eps
  *   p: 0 raw P, 1 stats float2[B][C] = (mean, 1/sqrt(var+eps)), 2 |0 scratch (bf16 plans: one
  *      coalesced pass into per-block partials + ordered finalize; fp32 plans / no scratch: exact
  *      two-pass kernel)
@@ -121,7 +125,9 @@
  *      5 Cout_pad (rows of Wf, 0 = Cout), 6 Kd (K extent of Wd, 0 = Cout_pad); everything beyond the real Cout x Cin is zero:
  *      that is how channel counts that are not multiples of 8 / 16 run (zero-padded tensors, K overrun of the MFMA conv),
  *      7 kind: 0 conv3x3 (W [Cout][Cin][3][3]); 1 transposed 2x2 stride 2 (W [Cin][Cout][2][2] -> Wf [9][4*Cout][Cin_pad],
- *      Wd [9][Cout_d][Kd >= 4*Cout], centre tap only)
+ *      Wd [9][Cout_d][Kd >= 4*Cout], centre tap only); 2 conv3x3 stride 2 in its 2x2 space-to-depth form (Cin = C, Cin_pad = Cout_d = 4C,
+ *      flags = 3): Wf [4][Cout_pad][4C] with tap (dy,dx), K index (py,px,c) = W[co][c][2dy+py][2dx+px] (0 where an index is 3),
+ *      Wd [(ty,tx)][4C][Kd] = Wf[(1-ty,1-tx)] transposed
  *   p: 0 W fp32 OIHW, 1 Wf [9][Cout_pad][Cin_pad], 2 |0 Wd [9][Cout_d][Kd] (taps flipped, in/out swapped: data gradient)
  * UNPREP_WGRAD      i: 0 Cout, 1 Cin, 2 Cin_w, 3 accumulate, 4 Cout_pad (rows of dWk, 0 = Cout), 5 kind (as PREP_WEIGHTS)
  *                   p: 0 dWk fp32 [9][Cout_pad][Cin_w], 1 dW fp32 OIHW (padded rows / columns dropped)

@@ -151,8 +151,50 @@ class Sim:
         z = torch.zeros(Wp + 1, C)
         return torch.cat([z, src.reshape(npix, C), z], 0), npix
 
+    @staticmethod
+    def _s2d(src, h, w):
+        """[B][2h+2][2w+2][C] -> the space-to-depth view X' [B][h+2][w+2][4C] over PADDED coordinates (row h+1 / column w+1 are zero):
+        X'[Y][X][(py, px, c)] = src[2Y + py][2X + px][c]  (fnet_conv_mfma.hip, MODE 1)"""
+        B, _, _, C = src.shape
+        x = src.reshape(B, h + 1, 2, w + 1, 2, C).permute(0, 1, 3, 2, 4, 5).reshape(B, h + 1, w + 1, 4 * C)
+        out = torch.zeros(B, h + 2, w + 2, 4 * C)
+        out[:, :h + 1, :w + 1] = x
+        return out
+
+    def _conv_s2(self, r):
+        npix, Wp, cin, ldc_in, coff_in, cout, ldc_out, coff_out, impl, mode, h, C = r.i[:12]
+        w = Wp - 2
+        Wk = r.p[1].buf.tensor.float()                     # [4][cout][K], K-blocked [K/16][4][cout][16]
+        K = Wk.shape[2]
+        assert impl == rt.CONV_MFMA and tuple(Wk.shape[:2]) == (4, cout) and cin <= K < cin + 16
+        Wk = Wk.reshape(K // 16, 4, cout, 16).permute(1, 2, 0, 3).reshape(4, cout, K)[:, :, :cin]
+        if mode == 1:
+            assert cin == 4 * C
+            src = self._s2d(self.rd(r.p[0], C, ldc_in, coff_in), h, w)
+            first = -(Wp + 1)                               # the 2x2 window reaches up / left
+        else:
+            assert cout == 4 * C
+            src = self.rd(r.p[0], cin, ldc_in, coff_in)
+            first = 0
+        B = src.shape[0]
+        xs, n = self._flat_conv_inputs(src, Wp)
+        assert n == npix
+        out = torch.zeros(npix, cout)
+        for t in range(4):
+            off = first + (t // 2) * Wp + (t % 2)
+            out += xs[Wp + 1 + off: Wp + 1 + off + npix] @ Wk[t].t()
+        if r.p[2] is not None:
+            out += self.flat(r.p[2])[:cout].float()
+        if mode == 1:
+            self.wr(r.p[3], cout, ldc_out, coff_out, out.view(B, h + 2, w + 2, cout))
+        else:
+            g = out.view(B, h + 2, w + 2, 2, 2, C)[:, :h + 1, :w + 1].permute(0, 1, 3, 2, 4, 5).reshape(B, 2 * h + 2, 2 * w + 2, C)
+            self.wr(r.p[3], C, ldc_out, coff_out, g)
+
     def op_CONV3X3(self, r):
         npix, Wp, cin, ldc_in, coff_in, cout, ldc_out, coff_out, impl = r.i[:9]
+        if len(r.i) > 9 and r.i[9]:
+            return self._conv_s2(r)
         src = self.rd(r.p[0], cin, ldc_in, coff_in)
         Wk = r.p[1].buf.tensor.float()                     # [9][cout][K], K = cin (K = cin rounded up to 16 for the MFMA kernel)
         K = Wk.shape[2]
@@ -173,6 +215,17 @@ class Sim:
 
     def op_WGRAD(self, r):
         npix, Wp, cin, ldc_in, coff_in, cout, ldc_do, coff_do, impl, cin_w = r.i[:10]
+        if len(r.i) > 13 and r.i[13]:                       # stride-2 convolution in its 2x2 space-to-depth form
+            h, C = r.i[11], r.i[14]
+            src = self._s2d(self.rd(r.p[0], C, ldc_in, coff_in), h, Wp - 2)
+            dout = self.rd(r.p[1], cout, ldc_do, coff_do).reshape(npix, cout)
+            xs, _ = self._flat_conv_inputs(src, Wp)
+            dWk = r.p[2].buf.tensor
+            assert cin == 4 * C and tuple(dWk.shape[:2]) == (4, cout)
+            for t in range(4):
+                off = -(Wp + 1) + (t // 2) * Wp + (t % 2)
+                dWk[t, :, :cin] += dout.t() @ xs[Wp + 1 + off: Wp + 1 + off + npix]
+            return
         src = self.rd(r.p[0], cin, ldc_in, coff_in)
         dout = self.rd(r.p[1], cout, ldc_do, coff_do).reshape(npix, cout)
         xs, _ = self._flat_conv_inputs(src, Wp)
@@ -425,6 +478,8 @@ class Sim:
         blocked = r.i[4] if len(r.i) > 4 else 0
         if len(r.i) > 7 and r.i[7] == 1:
             return self._prep_transposed(r)
+        if len(r.i) > 7 and r.i[7] == 2:
+            return self._prep_s2(r)
         cop = r.i[5] if len(r.i) > 5 and r.i[5] else cout          # padded rows / columns are zeros
         kd = r.i[6] if len(r.i) > 6 and r.i[6] else cop
         W = self.flat(r.p[0])[: cout * cin * 9].view(cout, cin, 9).float()
@@ -439,6 +494,29 @@ class Sim:
             if blocked & 2:
                 Wd = Wd.reshape(9, cout_d, kd // 16, 16).permute(2, 0, 1, 3).reshape(9, cout_d, kd)
             r.p[2].buf.tensor.copy_(Wd.to(self.T))
+
+    def _prep_s2(self, r):
+        """Conv2d(C, cout, 3, stride 2) as a 2x2-tap convolution over the space-to-depth view: tap (dy, dx), K index (py, px, c) carries
+        W[co][c][2dy + py][2dx + px] (zero where an index would be 3); Wd[(ty, tx)][k][co] = Wf[(1 - ty, 1 - tx)][co][k]"""
+        cout, C = r.i[:2]
+        cop, kd = r.i[5], r.i[6]
+        W = self.flat(r.p[0])[: cout * C * 9].view(cout, C, 3, 3).float()
+        Wf = torch.zeros(4, cop, 4 * C)
+        for dy in range(2):
+            for dx in range(2):
+                for py in range(2):
+                    for px in range(2):
+                        ky, kx = 2 * dy + py, 2 * dx + px
+                        if ky <= 2 and kx <= 2:
+                            ph = py * 2 + px
+                            Wf[dy * 2 + dx, :cout, ph * C:(ph + 1) * C] = W[:, :, ky, kx]
+        K = 4 * C
+        r.p[1].buf.tensor.copy_(Wf.reshape(4, cop, K // 16, 16).permute(2, 0, 1, 3).reshape(4, cop, K).to(self.T))
+        if r.p[2] is not None:
+            Wd = torch.zeros(4, K, kd)
+            for td in range(4):
+                Wd[td, :, :cop] = Wf[3 - td].t()
+            r.p[2].buf.tensor.copy_(Wd.reshape(4, K, kd // 16, 16).permute(2, 0, 1, 3).reshape(4, K, kd).to(self.T))
 
     def _prep_transposed(self, r):
         """ConvTranspose2d(k=2, s=2) weight [ci][co][a][b] as a centre-tap convolution into 4*cout channels, phase q = 2a+b outermost"""
@@ -481,6 +559,19 @@ class Sim:
                 d += v
             else:
                 d.copy_(v)
+            return
+        if len(r.i) > 5 and r.i[5] == 2:                            # stride-2 3x3 in 2x2 form: dW[co][c][ky][kx] from tap (ky>>1, kx>>1), phase (ky&1, kx&1)
+            t = r.p[0].buf.tensor
+            v = torch.zeros(cout, cin, 3, 3)
+            for ky in range(3):
+                for kx in range(3):
+                    ph = (ky & 1) * 2 + (kx & 1)
+                    v[:, :, ky, kx] = t[(ky >> 1) * 2 + (kx >> 1), :cout, ph * cin:(ph + 1) * cin]
+            d = self.flat(r.p[1])[: cout * cin * 9]
+            if accumulate:
+                d += v.reshape(-1)
+            else:
+                d.copy_(v.reshape(-1))
             return
         dWk = r.p[0].buf.tensor[:, :cout, :cin]
         v = dWk.permute(1, 2, 0).reshape(-1)

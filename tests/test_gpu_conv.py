@@ -89,3 +89,68 @@ def test_big_tile_selected_at_full_size():
     pb, ops = _mk(24, 128, 128, 64, 128, 64, 0, 128, 0, "bf16", "mfma")
     failures = lockstep(pb, ops[:1])
     assert not failures, "\n".join(failures)
+
+
+S2_SHAPES = [
+    # B, h,  w,  C (per phase), Cout, ldc_full, coff_full     (full-resolution image 2h x 2w)
+    (2, 16, 16, 32, 32, 64, 32),        # the cat-buffer skip slice of the training plan
+    (3, 20, 12, 64, 64, 64, 0),         # several images per tile, partial tiles
+    (1, 64, 64, 32, 64, 96, 32),
+    (2, 8, 8, 128, 128, 256, 128),
+    (1, 6, 130, 32, 32, 32, 0),         # wide rows
+    (5, 3, 5, 64, 128, 64, 0),          # tiny images: a tile spans several of them
+]
+
+
+def _mk_s2(B, h, w, C, cout, ldf, cof):
+    """Stride-2 convolution in its 2x2 space-to-depth form: forward (CONV3X3 mode 1), data gradient (mode 2), weight gradient (WGRAD mode 1)."""
+    pb = PlanBuilder(tiny_cfg(base_channels=16), 1, 16, 16, dtype="bf16", conv_impl="mfma")
+    pb.bufs.clear()
+    pb.B = B
+    g = torch.Generator().manual_seed(B * 1000 + h + C)
+    T = torch.bfloat16
+    full = pb.new_buf("full", (B, 2 * h + 2, 2 * w + 2, ldf), "T")
+    full.tensor = torch.randn(full.shape, generator=g).to(T)
+    wf = pb.new_buf("wf", (4, cout, 4 * C), "T")
+    wf.tensor = (torch.randn(wf.shape, generator=g) / (4 * C) ** 0.5).to(T)
+    wd = pb.new_buf("wd", (4, 4 * C, (cout + 15) // 16 * 16), "T")
+    wd.tensor = (torch.randn(wd.shape, generator=g) / (4 * cout) ** 0.5).to(T)
+    bias = pb.new_buf("bias", (cout,), "f32")
+    bias.tensor = torch.randn(cout, generator=g)
+    half = pb.new_buf("half", (B, h + 2, w + 2, cout), "T")
+    half.tensor = torch.full(half.shape, 7.0).to(T)
+    dout = pb.new_buf("dout", (B, h + 2, w + 2, cout), "T")
+    d = torch.randn(dout.shape, generator=g)
+    d[:, 0] = 0; d[:, -1] = 0; d[:, :, 0] = 0; d[:, :, -1] = 0
+    dout.tensor = d.to(T)
+    dfull = pb.new_buf("dfull", (B, 2 * h + 2, 2 * w + 2, ldf), "T")
+    dfull.tensor = torch.full(dfull.shape, 5.0).to(T)
+    dwk = pb.new_buf("dwk", (4, cout, 4 * C), "f32")
+    dwk.tensor = torch.randn(dwk.shape, generator=g) * 0.01
+    slab = pb.new_buf("slab", (2048 * 9 * 32 * 32,), "f32")
+    slab.tensor = torch.zeros(slab.shape)
+    ops = []
+    pb.e_conv_s2(ops, PV(full, C, cof), wf, Ref(bias), PV(half, cout), 1, tag="s2 forward")
+    pb.e_conv_s2(ops, PV(dout, cout), wd, None, PV(dfull, C, cof), 2, tag="s2 dgrad")
+    npix = B * (h + 2) * (w + 2)
+    pb.op(ops, "WGRAD", [npix, w + 2, 4 * C, ldf, cof, cout, cout, 0, rt.CONV_MFMA, 4 * C, B, h, 2048, 1, C],
+          p=[Ref(full), Ref(dout), Ref(dwk), Ref(slab)], tag="s2 wgrad")
+    return pb, ops
+
+
+@pytest.mark.parametrize("shape", S2_SHAPES, ids=[f"B{s[0]}_{s[1]}x{s[2]}_{s[3]}to{s[4]}" for s in S2_SHAPES])
+def test_stride2_space_to_depth_kernels(shape):
+    pb, ops = _mk_s2(*shape)
+    failures = lockstep(pb, ops)
+    assert not failures, "\n".join(failures)
+
+
+def test_stride2_big_tile_kernels():
+    """The same shapes through the 8-wave tiles (FNET_CONV_TILE=big, read once per process: a child process)."""
+    if os.environ.get("FNET_CONV_TILE"):
+        pytest.skip("already inside the forced-tile child")
+    env = dict(os.environ, FNET_CONV_TILE="big")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k", "test_stride2_space_to_depth_kernels",
+                        "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert f"{len(S2_SHAPES)} passed" in r.stdout, r.stdout[-2000:]

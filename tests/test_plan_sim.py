@@ -182,3 +182,41 @@ def test_clip_adam_step_matches_oracle():
         plan.pb.params.tensor.copy_(pack_params(plan.pb, p))
         plan.m.tensor.copy_(pack_params(plan.pb, m))
         plan.v.tensor.copy_(pack_params(plan.pb, v))
+
+
+@pytest.mark.parametrize("pm", ["replicate", "zeros", "reflect", "circular"])
+def test_stride2_space_to_depth_form_equals_full_resolution_form(pm, monkeypatch):
+    """bf16 MFMA plans run Conv2d(C, C, 3, stride=2) (ml/models/unet.py:90-91) as a 2x2-tap convolution over the space-to-depth view of
+    its input (CONV3X3 modes 1 / 2, WGRAD mode 1, PREP_WEIGHTS / UNPREP_WGRAD kind 2) instead of a full-resolution convolution +
+    SUBSAMPLE_BIAS / ZERO_INSERT.  The twin interprets both forms of the same bf16 plan (MFMA weight layouts and all), here on fp32
+    storage so that the two differ by summation order only: same loss, prediction and gradients; the full-resolution form is the one
+    the other tests of this file pin to the oracle."""
+    import fluidnet_amd.engine.runtime as rt
+    cfg = tiny_cfg(base_channels=16, depth=2, padding_mode=pm, dropout=0.1)
+    lc = loss_c2(32, padding_mode=pm)
+    params = orc.make_params(cfg, seed=11)
+    x0, y, mk = orc.synth_batch(2, 2, 32, seed=77)
+    out = {}
+    for s2 in ("1", "0"):
+        monkeypatch.setenv("FNET_S2", s2)
+        plan = RolloutTrainPlan(cfg, lc, 2, 32, 32, 2, dtype="bf16", seed=3, clip_norm=None)
+        pb = plan.pb
+        modes = [r.i[9] for sec in plan.sections.values() for r in sec if rt.OPNAME[r.code] == "CONV3X3" and len(r.i) > 9]
+        assert (1 in modes and 2 in modes) == (s2 == "1")
+        for b in pb.bufs:                       # fp32 storage for every activation / weight-image buffer
+            if b.kind == "T" and not b.external and b.parent is None:
+                b.tensor = torch.zeros(b.shape)
+        plan.bind("cpu", pack_params(pb, params), torch.zeros(pb.n_params_padded))
+        plan.x0.tensor.copy_(torch.from_numpy(x0))
+        plan.y.tensor.copy_(torch.from_numpy(y))
+        plan.masks.tensor.copy_(torch.from_numpy(mk))
+        sim = Sim(rt.F32)
+        for s in ("fwd", "fin", "bwd"):
+            sim.run(plan.sections[s])
+        out[s2] = (plan.loss_dict()["total"], plan.tapes[-1].pred.tensor.clone(), pb.grads.tensor.clone(), pb)
+    (l1, p1, g1, pb1), (l0, p0, g0, pb0) = out["1"], out["0"]
+    assert abs(l1 - l0) < 2e-6 * abs(l0)
+    assert float((p1 - p0).abs().max()) < 2e-3
+    for k_ in pb1.shapes:
+        e = relerr(unpack(pb1, g1, k_), unpack(pb0, g0, k_))
+        assert e < 2e-4, (k_, e)

@@ -894,14 +894,14 @@ class PlanBuilder:
         self.emit_zero(ops, self.grads)
         self.emit_zero(ops, self.dwk_slab)
 
-    def emit_unprep(self, ops, prefixes=None, skip=(), lane: int = 0) -> List[str]:
+    def emit_unprep(self, ops, prefixes=None, skip=(), lane: int = 0, accumulate: bool = False) -> List[str]:
         """dWk (tap-major accumulators) -> OIHW gradients in grads_flat, for the convolutions whose name starts with one of `prefixes`
         (default: all) and is not in `skip`; returns the names emitted."""
         done = []
         for name, c in self.convs.items():
             if name in skip or (prefixes is not None and not name.startswith(tuple(prefixes))):
                 continue
-            self.op(ops, "UNPREP_WGRAD", [c["Cout"], c["Cin"], 4 * c["Cin_pad"] if c.get("s2") else c["Cin_pad"], 0, c["Cout_pad"],
+            self.op(ops, "UNPREP_WGRAD", [c["Cout"], c["Cin"], 4 * c["Cin_pad"] if c.get("s2") else c["Cin_pad"], 1 if accumulate else 0, c["Cout_pad"],
                                           2 if c.get("s2") else c.get("tr", 0)],
                     p=[Ref(c["dWk"]), self.gref(name + ".weight")], tag=name, lane=lane)
             done.append(name)

@@ -68,8 +68,7 @@ class UNetEngine:
             zero: List[OpRec] = []
             pb.emit_zero(zero, pb.dwk_slab)
             unprep: List[OpRec] = []
-            for name, c in pb.convs.items():
-                pb.op(unprep, "UNPREP_WGRAD", [c["Cout"], c["Cin"], c["Cin_pad"], 1, c["Cout_pad"], c.get("tr", 0)], p=[Ref(c["dWk"]), pb.gref(name + ".weight")], tag=name)
+            pb.emit_unprep(unprep, accumulate=True)        # .grad accumulates across backward calls, as autograd's does
             allocate(pb, self.device)
             self._prep, self._zero_dwk, self._unprep_acc = lower(pb, prep), lower(pb, zero), lower(pb, unprep)
         else:

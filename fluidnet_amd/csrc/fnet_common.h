@@ -131,14 +131,16 @@ __host__ __device__ __forceinline__ int fold_list(int i, int n, int pm, int out[
 // transcendental issues (v_rcp, v_exp) + 9 FMAs instead of libm erff's ~40 instructions: the elementwise kernels are
 // VALU-bound on GELU, not HBM-bound, with the libm version.
 __device__ __forceinline__ float gelu_phi(float u, float& E) {
-    const float z = fabsf(u) * 0.70710678118654752f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.f));
-    E = __expf(-z * z);
-    float p = fmaf(1.061405429f, t, -1.453152027f);
-    p = fmaf(p, t, 1.421413741f);
-    p = fmaf(p, t, -0.284496736f);
-    p = fmaf(p, t, 0.254829592f);
-    const float q = 0.5f * p * t * E;  // = 0.5*erfc(z)
+    // w = |u| * sqrt(log2(e) / 2): E = exp(-u^2/2) = exp2(-w^2) is one multiply + v_exp_f32; the A&S argument z = |u|/sqrt2 = w / sqrt(log2 e)
+    // is folded into the rational's coefficient, the 0.5 of 0.5*erfc into the polynomial's
+    const float w = fabsf(u) * 0.84932180028801904f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.2727374809f, w, 1.f));        // 0.3275911 / sqrt(log2 e)
+    E = __builtin_amdgcn_exp2f(-w * w);
+    float p = fmaf(0.5307027145f, t, -0.7265760135f);
+    p = fmaf(p, t, 0.7107068705f);
+    p = fmaf(p, t, -0.142248368f);
+    p = fmaf(p, t, 0.127414796f);
+    const float q = p * t * E;             // = 0.5*erfc(|u|/sqrt2)
     return u < 0.f ? q : 1.f - q;
 }
 template <int ACT>

@@ -504,6 +504,10 @@ __global__ __launch_bounds__(256) void k_inact_bwd_reduce(const T* __restrict__ 
 #pragma unroll
                         for (int k = 0; k < 8; ++k) acc[k] += a2[u].v[k];
                         if (f2) fold_extras8<T>(g2img, yy[u], xx[u], H, W, ldc_g2, pm, acc);
+                    } else if (sizeof(T) == 2) {
+                        // single source: only a folded pixel is a sum that needs rounding to the stored type (see below)
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) acc[k] = bf2f(f2bf(acc[k]));
                     }
                 }
                 Vec8<T> go;
@@ -516,7 +520,7 @@ __global__ __launch_bounds__(256) void k_inact_bwd_reduce(const T* __restrict__ 
                     const float xh = fmaf(r[u].v[k], xa[k], xb[k]);
                     const float uu = fmaf(xh, gam[k], bet[k]);
                     float gq = go.v[k];
-                    if (sizeof(T) == 2) gq = bf2f(f2bf(gq));
+                    if (sizeof(T) == 2 && G2) gq = bf2f(f2bf(gq));   // (one source: a stored value, or rounded where it was folded)
                     const float dz = gq * dsc[k] * act_bwd_t<ACT>(uu);
                     s[k] += dz;
                     t[k] = fmaf(dz, xh, t[k]);

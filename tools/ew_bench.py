@@ -12,6 +12,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 LAYERS = [(128, 32), (128, 64), (64, 64), (64, 128), (32, 128), (16, 256)]  # (H, C)
+ACTN = os.environ.get("FNET_EW_ACT", "gelu")          # activation of the timed kernels
+if os.environ.get("FNET_EW_LAYERS"):                     # e.g. "128x64,64x128"
+    LAYERS = [tuple(int(v) for v in t.split("x")) for t in os.environ["FNET_EW_LAYERS"].split(",")]
 
 
 def run(B=64, reps=12):
@@ -21,7 +24,7 @@ def run(B=64, reps=12):
     from fluidnet_amd.models.unet import UNetConfig
     cfg = UNetConfig(in_channels=6, base_channels=32, depth=3, norm="instance", act="gelu", upsample="bilinear", padding_mode="replicate",
                      use_residual=True)
-    print("lib:", rt.LIB_PATH, "FNET_CG_BLOCKS=", os.environ.get("FNET_CG_BLOCKS"))
+    print("lib:", rt.LIB_PATH, "FNET_CG_BLOCKS=", os.environ.get("FNET_CG_BLOCKS"), "act", ACTN)
     for (H, C) in LAYERS:
         tensor_mb = B * (H + 2) * (H + 2) * C * 2 / 1e6
         for mode in ("warm", "cold"):
@@ -45,18 +48,22 @@ def run(B=64, reps=12):
             per = {}
             for bufs in sets:
                 ops = []
-                pb.op(ops, "IN_STATS", [B, H, H, C, C, 0, sc.numel, 0], f=[1e-5], p=[Ref(bufs["raw"]), Ref(bufs["stats"]), Ref(sc)], tag="stats")
-                pb.op(ops, "APPLY", [B, H, H, C, C, 0, 0, 0, C, 0, rt.ACT["gelu"], rt.PAD["replicate"], 3, 1234], f=[0.1],
+                pb.op(ops, "IN_STATS", [B, H, H, C, C, 0, sc.numel], f=[1e-5], p=[Ref(bufs["raw"]), Ref(bufs["stats"]), Ref(sc)], tag="stats")
+                pb.op(ops, "APPLY", [B, H, H, C, C, 0, 0, 0, C, 0, rt.ACT[ACTN], rt.PAD["replicate"], 3, 1234], f=[0.1],
                       p=[Ref(bufs["raw"]), Ref(bufs["stats"]), Ref(gamma), Ref(beta), None, Ref(bufs["act"])], tag="apply")
-                pb.op(ops, "INACT_BWD_REDUCE", [B, H, H, C, C, 0, 0, 0, C, 0, C, 0, 1, 0, rt.ACT["gelu"], rt.PAD["replicate"], 3, 1234], f=[0.1],
+                pb.op(ops, "INACT_BWD_REDUCE", [B, H, H, C, C, 0, 0, 0, C, 0, C, 0, 1, 0, rt.ACT[ACTN], rt.PAD["replicate"], 3, 1234], f=[0.1],
                       p=[Ref(bufs["g"]), None, Ref(bufs["raw"]), Ref(bufs["stats"]), Ref(gamma), Ref(beta), Ref(bufs["G"]), Ref(bufs["S"]), None, None],
                       tag="bwd_reduce")
-                pb.op(ops, "INACT_BWD_APPLY", [B, H, H, C, C, 0, C, 0, C, 0, rt.ACT["gelu"], 3, 1234], f=[0.1],
+                pb.op(ops, "INACT_BWD_APPLY", [B, H, H, C, C, 0, C, 0, C, 0, rt.ACT[ACTN], 3, 1234], f=[0.1],
                       p=[Ref(bufs["G"]), Ref(bufs["raw"]), Ref(bufs["stats"]), Ref(gamma), Ref(beta), Ref(bufs["S"]), Ref(bufs["draw"])], tag="bwd_apply")
+                # the single-source form of pass 1 (no G written: the common case in the training plan)
+                pb.op(ops, "INACT_BWD_REDUCE", [B, H, H, C, C, 0, 0, 0, C, 0, C, 0, 1, 0, rt.ACT[ACTN], rt.PAD["replicate"], 3, 1234], f=[0.1],
+                      p=[Ref(bufs["g"]), None, Ref(bufs["raw"]), Ref(bufs["stats"]), Ref(gamma), Ref(beta), None, Ref(bufs["S"]), None, None],
+                      tag="bwd_reduce1")
                 arr = lower(pb, ops)
-                for k, name in enumerate(("stats", "apply", "bwd_reduce", "bwd_apply")):
+                for k, name in enumerate(("stats", "apply", "bwd_reduce", "bwd_apply", "bwd_reduce1")):
                     per.setdefault(name, []).append(arr[k:k + 1])
-            traffic = {"stats": 1, "apply": 2, "bwd_reduce": 3, "bwd_apply": 3}
+            traffic = {"stats": 1, "apply": 2, "bwd_reduce": 3, "bwd_apply": 3, "bwd_reduce1": 2}
             out = []
             for name, arrs in per.items():
                 for a in arrs:

@@ -2,8 +2,8 @@
 HBM traffic summary bench.py reports as roofline.traffic.
 
     cd /tmp && export TMPDIR=/tmp
-    rocprofv3 --pmc FETCH_SIZE --output-format csv -d out/pmc_f -o f -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile
-    rocprofv3 --pmc WRITE_SIZE --output-format csv -d out/pmc_w -o w -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile
+    rocprofv3 --pmc FETCH_SIZE --output-format csv -d out/pmc_f -o f -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-rollout
+    rocprofv3 --pmc WRITE_SIZE --output-format csv -d out/pmc_w -o w -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-rollout
     python tools/pmc_traffic.py out/pmc_f/f_counter_collection.csv out/pmc_w/w_counter_collection.csv profiles/r1d_pmc_traffic.json
 
 Units and corrections (MI355X_MICROARCH.md, HBM section): both counters are in KiB; on gfx950 FETCH_SIZE tallies the 128-B
@@ -34,7 +34,7 @@ def _load(path, counter):
 def main(fetch_csv, write_csv, out_json, command=""):
     F = _load(fetch_csv, "FETCH_SIZE")
     W = _load(write_csv, "WRITE_SIZE")
-    out = {"command": command or "python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile",
+    out = {"command": command or "python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-rollout",
            "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 per launch (gfx950 FETCH_SIZE counts 128-B requests as 64 B)",
            "kernels": {}}
     for name, (n, kb) in sorted(F.items(), key=lambda kv: -kv[1][1]):

@@ -389,8 +389,8 @@ def main():
                           "parallelism": f"dp{world}", "final_loss": round(loss["total"], 6),
                           "hbm_bytes_allocated": st.bytes}}
         flops_step = sum(r.flops for s in st.plan.sections.values() for r in s)
-        out["config"]["algorithmic_tflop_per_step"] = round(flops_step / 1e12, 4)
-        out["config"]["end_to_end_tflops"] = round(flops_step * steps / dt / 1e12 * 1.0, 2)
+        out["config"]["algorithmic_tflop_per_step"] = round(flops_step * world / 1e12, 4)          # whole job (all ranks), like `value`
+        out["config"]["end_to_end_tflops"] = round(flops_step * world * steps / dt / 1e12, 2)
         if rank == 0 and not a.no_profile:
             agg = profile_ops(st.plan._lowered, st.plan.sections, a.dump_ops)
             tot = sum(v["ms"] for v in agg.values())

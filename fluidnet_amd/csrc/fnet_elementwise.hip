@@ -149,6 +149,11 @@ struct PixWalk {
     }
 };
 template <int N> struct IntC { static constexpr int value = N; };
+// Element offset of pixel `pix` of an image with `ldc` channels per pixel, in 32-bit arithmetic on the full-rate 24-bit multiplier
+// (v_mul_lo_u32 and the 64-bit forms hipcc picks for size_t indices run at quarter rate, and the channel-group kernels form two or
+// three such addresses per pixel).  Launchers check (H+2)(W+2) < 2^24, ldc < 2^24 and (H+2)(W+2)*ldc < 2^31.
+__device__ __forceinline__ uint32_t pix_off(uint32_t pix, int ldc) { return __umul24(pix, (uint32_t)ldc); }
+__device__ __forceinline__ uint32_t pix_of(int yp, int xp, int Wp) { return __umul24((uint32_t)yp, (uint32_t)Wp) + (uint32_t)xp; }
 // v or +0.0 by bit mask (keep = 0xffffffff / 0): a select that the compiler cannot turn back into a branch around the
 // arithmetic that produced v, and that also kills a NaN/Inf computed from an unwritten ring pixel
 __device__ __forceinline__ float keep_bits(float v, uint32_t keep) { return __uint_as_float(__float_as_uint(v) & keep); }
@@ -371,9 +376,9 @@ __global__ __launch_bounds__(256) void k_apply(const T* __restrict__ raw, const 
             sx = sx < 0 ? xlo : (sx >= W ? xhi : sx);
             keep[u] = (sy | sx) < 0 ? 0u : 0xffffffffu;    // zero padding: load pixel (0,0), discard it below
             sy = max(sy, 0); sx = max(sx, 0);
-            const size_t sp = (size_t)(sy + 1) * Wp + sx + 1;
-            r[u].load(rbase + sp * ldc_raw);
-            if (RES) q[u].load(sbase + sp * ldc_res);
+            const uint32_t sp = pix_of(sy + 1, sx + 1, Wp);
+            r[u].load(rbase + pix_off(sp, ldc_raw));
+            if (RES) q[u].load(sbase + pix_off(sp, ldc_res));
             w.step();
         }
 #pragma unroll
@@ -385,7 +390,7 @@ __global__ __launch_bounds__(256) void k_apply(const T* __restrict__ raw, const 
                 if (RES) v += q[u].v[k];
                 o.v[k] = keep_bits(v, keep[u]);
             }
-            o.store_nt(dbase + (size_t)(p + u * ps) * ldc_dst);
+            o.store_nt(dbase + pix_off((uint32_t)(p + u * ps), ldc_dst));
         }
     };
     constexpr int U = FNET_EW_U;       // pixels per trip, all loads first
@@ -476,15 +481,15 @@ __global__ __launch_bounds__(256) void k_inact_bwd_reduce(const T* __restrict__ 
             constexpr int UU = decltype(uc)::value;
             constexpr bool G2 = decltype(gc)::value != 0;
             Vec8<T> a1[UU], a2[UU], r[UU];
-            size_t pix[UU];
+            uint32_t pix[UU];
             int yy[UU], xx[UU];
 #pragma unroll
             for (int u = 0; u < UU; ++u) {
                 yy[u] = w.y; xx[u] = w.x;
-                pix[u] = (size_t)(w.y + 1) * Wp + w.x + 1;
-                a1[u].load(g1img + pix[u] * ldc_g1);
-                if (G2) a2[u].load(g2img + pix[u] * ldc_g2);
-                r[u].load(rbase + pix[u] * ldc_raw);
+                pix[u] = pix_of(w.y + 1, w.x + 1, Wp);
+                a1[u].load(g1img + pix_off(pix[u], ldc_g1));
+                if (G2) a2[u].load(g2img + pix_off(pix[u], ldc_g2));
+                r[u].load(rbase + pix_off(pix[u], ldc_raw));
                 w.step();
             }
 #pragma unroll
@@ -513,7 +518,7 @@ __global__ __launch_bounds__(256) void k_inact_bwd_reduce(const T* __restrict__ 
                 Vec8<T> go;
 #pragma unroll
                 for (int k = 0; k < 8; ++k) go.v[k] = acc[k];
-                if (Gbase) go.store_nt(Gbase + pix[u] * ldc_G);
+                if (Gbase) go.store_nt(Gbase + pix_off(pix[u], ldc_G));
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     // use the value as stored (bf16-rounded in bf16 mode) so that pass 2 sees the same G
@@ -596,9 +601,9 @@ __global__ __launch_bounds__(256) void k_inact_bwd_apply(const T* __restrict__ G
         for (int u = 0; u < UU; ++u) {
             keep[u] = (w.y == 0 || w.y == Hp - 1 || w.x == 0 || w.x == Wp - 1) ? 0u : 0xffffffffu;   // ring: loaded all the same (valid memory), zeroed below
             yy[u] = w.y - 1; xx[u] = w.x - 1;
-            const size_t pu = (size_t)(p + u * ps);
-            g[u].load(Gbase + pu * ldc_G);
-            r[u].load(rbase + pu * ldc_raw);
+            const uint32_t pu = (uint32_t)(p + u * ps);
+            g[u].load(Gbase + pix_off(pu, ldc_G));
+            r[u].load(rbase + pix_off(pu, ldc_raw));
             w.step();
         }
 #pragma unroll
@@ -618,7 +623,7 @@ __global__ __launch_bounds__(256) void k_inact_bwd_apply(const T* __restrict__ G
                 const float dz = g[u].v[k] * dsc[k] * act_bwd_t<ACT>(uu);
                 o.v[k] = keep_bits(WS ? fmaf(k0[k], dz, -fmaf(xh, k2[k], k1[k])) : k0[k] * (dz - k1[k] - xh * k2[k]), keep[u]);
             }
-            o.store_nt(dbase + (size_t)(p + u * ps) * ldc_d);
+            o.store_nt(dbase + pix_off((uint32_t)(p + u * ps), ldc_d));
         }
     };
     constexpr int U = FNET_EW_U;       // pixels per trip, all loads first
@@ -1080,6 +1085,14 @@ inline int cg_pixels_per_block(int npix, int B, int C, int* chunks_out, int targ
     return per;
 }
 inline bool cg_ok(int C, int B) { return C >= 8 && (C >> 3) <= kThreads && B > 0 && B < 65536; }
+// pix_off / pix_of: image-local pixel indices fit 24 bits and element offsets 31 bits for every stream (ldc) of the launch
+inline bool off_ok(int H, int W, int ldc_a, int ldc_b, int ldc_c = 8, int ldc_d = 8) {
+    const long long px = (long long)(H + 2) * (W + 2);
+    long long ld = ldc_a > ldc_b ? ldc_a : ldc_b;
+    if (ldc_c > ld) ld = ldc_c;
+    if (ldc_d > ld) ld = ldc_d;
+    return px < (1ll << 24) && ld < (1ll << 24) && px * ld < (1ll << 31);
+}
 
 }  // namespace
 
@@ -1146,7 +1159,7 @@ int fnet_op_apply(const FnetOp& op, hipStream_t st) {
     FNET_CHECK_ARG(vec_ok((void*)op.p[5], op.i[8], op.i[9], C, op.dtype));
     FNET_CHECK_ARG(op.i[10] >= 0 && op.i[10] <= 4 && op.i[11] >= 0 && op.i[11] <= 3);
     FNET_CHECK_ARG(op.p[1] == 0 || (op.p[2] != 0 && op.p[3] != 0));
-    FNET_CHECK_ARG(op.f[0] >= 0.f && op.f[0] < 1.f && cg_ok(C, B));
+    FNET_CHECK_ARG(op.f[0] >= 0.f && op.f[0] < 1.f && cg_ok(C, B) && off_ok(H, W, op.i[4], op.p[4] ? op.i[6] : 8, op.i[8]));
     int chunks;
     const int per = cg_pixels_per_block((H + 2) * (W + 2), B, C, &chunks, 768);
     DISPATCH_ACT(op.i[10], DISPATCH_T(op.dtype, hipLaunchKernelGGL((k_apply<T, ACT>), dim3(chunks, B), dim3(kThreads), 0, st,
@@ -1171,6 +1184,7 @@ int fnet_op_inact_bwd_reduce(const FnetOp& op, hipStream_t st) {
     FNET_CHECK_ARG(vec_ok_opt((void*)op.p[6], op.i[10], op.i[11], C, op.dtype));
     FNET_CHECK_ARG(op.p[6] != 0 || op.p[1] == 0);          // G may be omitted only for a single gradient source
     FNET_CHECK_ARG(op.p[3] && op.p[4] && op.p[5] && op.p[7] && cg_ok(C, B) && ((op.p[8] == 0) == (op.p[9] == 0)));
+    FNET_CHECK_ARG(off_ok(H, W, op.i[4], op.p[1] ? op.i[6] : 8, op.i[8], op.p[6] ? op.i[10] : 8));
     int chunks;
     const int per = cg_pixels_per_block(H * W, B, C, &chunks, 768);
     DISPATCH_ACT(op.i[14], DISPATCH_T(op.dtype,
@@ -1193,7 +1207,7 @@ int fnet_op_inact_bwd_apply(const FnetOp& op, hipStream_t st) {
     FNET_CHECK_ARG(vec_ok((void*)op.p[0], op.i[4], op.i[5], C, op.dtype));
     FNET_CHECK_ARG(vec_ok((void*)op.p[1], op.i[6], op.i[7], C, op.dtype));
     FNET_CHECK_ARG(vec_ok((void*)op.p[6], op.i[8], op.i[9], C, op.dtype));
-    FNET_CHECK_ARG(op.p[2] && op.p[3] && op.p[4] && op.p[5] && cg_ok(C, B));
+    FNET_CHECK_ARG(op.p[2] && op.p[3] && op.p[4] && op.p[5] && cg_ok(C, B) && off_ok(H, W, op.i[4], op.i[6], op.i[8]));
     FNET_CHECK_ARG((op.i[13] == 0 || op.i[13] == 1) && op.i[14] >= 0 && op.i[14] <= 3);
     int chunks;
     const int per = cg_pixels_per_block((H + 2) * (W + 2), B, C, &chunks, 768);

@@ -30,6 +30,9 @@ def _weights(cfg, seed):
     ("large-avgpool", orc.medium_config(dropout=0.0, base_channels=48, depth=4, downsample="avgpool"), 1, 64),
     ("small-medium-base20", orc.medium_config(dropout=0.0, base_channels=20, downsample="avgpool"), 2, 32),      # UNet_small-medium.yaml
     ("groupnorm-maxpool", tiny_cfg(norm="group", act="silu", downsample="maxpool", base_channels=16, group_norm_groups=4), 2, 32),
+    # GroupNorm over channel counts that run zero-padded (20 -> 24, 12 -> 16): the groups are formed over the REAL channels
+    ("groupnorm-base20", orc.medium_config(dropout=0.0, base_channels=20, norm="group", group_norm_groups=8, downsample="avgpool"), 2, 32),
+    ("groupnorm-base12", tiny_cfg(norm="group", base_channels=12, group_norm_groups=3), 2, 32),
 ])
 def test_native_rollout_equals_python_plan(name, cfg, B, R):
     params, flat = _weights(cfg, seed=3)

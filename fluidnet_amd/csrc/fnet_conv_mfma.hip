@@ -77,7 +77,7 @@ struct ConvTile {          // wave-uniform description of one (pixel tile, cout 
     int in_lane_off;       // per lane (MODE 0, 2)
     __amdgpu_buffer_rsrc_t rs;
 };
-constexpr int S2_MAXP = 8;  // MODE 1: DMA pieces per wave and stage whose gather offsets are kept in registers
+constexpr int S2_MAXP = 10; // DMA pieces per wave and stage whose per-lane source offsets are kept in registers (piece q = wave + NW*k <-> slot k)
 
 // exact a / d for 0 <= a < 2^24, d > 0, inv = 1.f / d
 __device__ __forceinline__ int fdiv24(int a, int d, float inv) {
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_conv3x3_dma(const 
         return (((ph >> 1) * Wps + (ph & 1)) * ldc_in + c0) * 2;
     };
 
-    auto tile_of = [&](int L, ConvTile& T, int (&so)[S2_MAXP]) -> bool {
+    auto tile_of = [&](int L, ConvTile& T) -> bool {
         // returns false when L is past the end or maps to a padding slot of the XCD layout
         if (L >= n_items) return false;
         const int xcd = L & 7, j = L >> 3;
@@ -164,8 +164,6 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_conv3x3_dma(const 
         T.f0 = (long long)mt * TMB;
         T.n0 = (j - (j / n_ntiles) * n_ntiles) * TN;
         if (MODE == 1) {
-#pragma unroll
-            for (int k = 0; k < S2_MAXP; ++k) so[k] = gather_off(T.f0, k);
             T.rs = rsg;
             T.in_lane_off = 0;
             return true;
@@ -179,27 +177,33 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_conv3x3_dma(const 
         T.in_lane_off = (int)(((long long)(lane >> 1) + (gbase - wpix)) * ldc_in + coff_in + dh * 8) * 2;
         return true;
     };
-    // one DMA piece (1 KB = 32 rows x 32 B) of stage s of tile T into stage buffer `buf`: pieces [0, npi) are the input run,
-    // [npi, npi + NPW) the weight slab.  k = the piece's register slot (q = wave + NW * k), sgo = stage_off(s) (MODE 1)
-    auto issue_piece = [&](const ConvTile& T, const int (&so)[S2_MAXP], int s, int sgo, int buf, int q, int k) {
-        unsigned char* wdst = smem + buf * bufsz;
-        if (q < npi) {
-            if (MODE == 1)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(T.rs, (lds_void_t*)(wdst + WB + q * 1024), 16, so[k], sgo, 0, 0);
-            else
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(T.rs, (lds_void_t*)(wdst + WB + q * 1024), 16,
-                                                         T.in_lane_off + q * in_piece_stride + s * (KC * 2), 0, 0, 0);
-        } else {
-            const int qw = q - npi;
-            const int row = qw * 32 + wrow;
-            const int t = row / TN;
-            int co = T.n0 + (row - t * TN);
-            co = co < Cout ? co : Cout - 1;
-            const int woff = (int)(((((size_t)s * NTAPS + t) * Cout + co) * 16 + dh * 8) * 2);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_void_t*)(wdst + qw * 1024), 16, woff, 0, 0, 0);
-        }
+    const int npieces = npi + NPW;                 // DMA pieces per stage
+    const int wstage = NTAPS * Cout * KC * 2;      // bytes of one stage's weight slab in the K-blocked layout
+    // Per-lane source offset of every piece this wave issues for tile T, stage 0 (slot k <-> piece q = wave + NW*k): computed once per tile,
+    // so that a piece inside the tap loops costs one scalar compare and the DMA instruction itself; the stage adds a wave-uniform offset
+    // (input: 32 B per stage, MODE 1: stage_off(s); weights: s * wstage) through the instruction's scalar offset.
+    auto piece_off = [&](const ConvTile& T, int q, int k) -> int {
+        if (q < npi) return MODE == 1 ? gather_off(T.f0, k) : T.in_lane_off + q * in_piece_stride;
+        const int row = (q - npi) * 32 + wrow;
+        const int t = row / TN;
+        int co = T.n0 + (row - t * TN);
+        co = co < Cout ? co : Cout - 1;
+        return ((t * Cout + co) * 16 + dh * 8) * 2;
     };
-    const int npieces = npi + NPW;                 // DMA pieces per stage (host: at most S2_MAXP per wave in MODE 1)
+    // (the 512 x 128 tile of the 3x3 form has no registers to spare -- 256 accumulators: it forms every offset where it is used)
+    constexpr int MAXP = (TN == 128 && MODE == 0) ? 0 : S2_MAXP;
+    auto piece_offsets = [&](const ConvTile& T, int (&po)[S2_MAXP]) {
+#pragma unroll
+        for (int k = 0; k < MAXP; ++k) po[k] = piece_off(T, wave + NW * k, k);
+    };
+    // one DMA piece (1 KB = 32 rows x 32 B) of stage s of tile T into the stage buffer at byte offset boff: pieces [0, npi) are the
+    // input run, [npi, npi + NPW) the weight slab; voff = the piece's per-lane offset (po[k], or piece_off for the rare pieces beyond
+    // the register slots), sin / sw = the stage's scalar offsets
+    auto issue_piece = [&](const ConvTile& T, int voff, int sin, int sw, int boff, int q) {
+        unsigned char* wdst = smem + boff;
+        if (q < npi) __builtin_amdgcn_raw_ptr_buffer_load_lds(T.rs, (lds_void_t*)(wdst + WB + q * 1024), 16, voff, sin, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_void_t*)(wdst + (q - npi) * 1024), 16, voff, sw, 0, 0);
+    };
 
     // fragment read addresses (bytes, relative to a stage buffer): taps x 2 pixel sub-tiles; weights: lane base + immediates
     unsigned xaddr[NTAPS][2];
@@ -221,9 +225,10 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_conv3x3_dma(const 
             for (int i = 0; i < 16; ++i) acc[ms][ns][i] = 0.f;
 
     ConvTile cur, nxt;
-    int so_cur[S2_MAXP], so_nxt[S2_MAXP];
-    bool have = tile_of(blockIdx.x, cur, so_cur);
+    int po[S2_MAXP];
+    bool have = tile_of(blockIdx.x, cur);
     if (!have) return;
+    piece_offsets(cur, po);
     int L = blockIdx.x;
     unsigned g = 0;                       // running stage counter: stage buffer = g & 1
 #if FNET_CONV_STAMPS
@@ -235,13 +240,13 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_conv3x3_dma(const 
 #define STAMP(x)
 #endif
     {
-        const int sgo = MODE == 1 ? stage_off(0) : 0;
+        const int sin = MODE == 1 ? stage_off(0) : 0;
 #pragma unroll
-        for (int k = 0; k < S2_MAXP; ++k) {
+        for (int k = 0; k < MAXP; ++k) {
             const int q = wave + NW * k;
-            if (q < npieces) issue_piece(cur, so_cur, 0, sgo, 0, q, k);
+            if (q < npieces) issue_piece(cur, po[k], sin, 0, 0, q);
         }
-        for (int q = wave + NW * S2_MAXP; q < npieces; q += NW) issue_piece(cur, so_cur, 0, sgo, 0, q, 0);   // MODE 0 / 2 only
+        for (int q = wave + NW * MAXP; q < npieces; q += NW) issue_piece(cur, piece_off(cur, q, 0), sin, 0, 0, q);   // wide images, MODE 0 / 2
     }
     while (true) {
         bool have_next = false;
@@ -256,15 +261,19 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_conv3x3_dma(const 
             // issued one piece per tap INSIDE the tap loop below: a piece costs the issuing wave 60-185 cycles, which hide behind
             // the four MFMAs of a tap instead of delaying every wave's first MFMA after the barrier.
             const bool last = s + 1 == nst;
-            if (last) { L += gridDim.x; have_next = tile_of(L, nxt, so_nxt); }
             ConvTile Ti = cur;             // by value (a reference to one of two structs would put both in scratch)
-            int so_i[S2_MAXP];
-#pragma unroll
-            for (int k = 0; k < S2_MAXP; ++k) so_i[k] = last ? so_nxt[k] : so_cur[k];
-            if (last) Ti = nxt;
+            if (last) {
+                // every piece of this tile has been issued: the offset registers now describe the block's next tile, whose stage 0
+                // is issued during this stage
+                L += gridDim.x;
+                have_next = tile_of(L, nxt);
+                if (have_next) piece_offsets(nxt, po);
+                Ti = nxt;
+            }
             const int si = last ? 0 : s + 1;
-            const int sgo = MODE == 1 ? stage_off(si) : 0;
-            const int nbuf = (g + 1) & 1;
+            const int sin = MODE == 1 ? stage_off(si) : si * (KC * 2);
+            const int sw = si * wstage;
+            const int nbuf = ((g + 1) & 1) ? bufsz : 0;
 #if FNET_CONV_ABLATE == 2
             const int qlim = 0;
 #else
@@ -289,7 +298,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_conv3x3_dma(const 
                 }
                 {
                     const int q = wave + NW * t;
-                    if (q < qlim) issue_piece(Ti, so_i, si, sgo, nbuf, q, t < S2_MAXP ? t : 0);
+                    if (q < qlim) issue_piece(Ti, t < MAXP ? po[t < MAXP ? t : 0] : piece_off(Ti, q, 0), sin, sw, nbuf, q);
                 }
                 __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of this tap's MFMAs (hipcc otherwise re-serialises them)
 #pragma unroll
@@ -304,11 +313,11 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_conv3x3_dma(const 
             }
             // more pieces per wave than taps (wide images; always in the 2x2 modes)
 #pragma unroll
-            for (int k = NTAPS; k < S2_MAXP; ++k) {
+            for (int k = NTAPS; k < MAXP; ++k) {
                 const int q = wave + NW * k;
-                if (q < qlim) issue_piece(Ti, so_i, si, sgo, nbuf, q, k);
+                if (q < qlim) issue_piece(Ti, po[k], sin, sw, nbuf, q);
             }
-            for (int q = wave + NW * (NTAPS > S2_MAXP ? NTAPS : S2_MAXP); q < qlim; q += NW) issue_piece(Ti, so_i, si, sgo, nbuf, q, 0);
+            for (int q = wave + NW * (MAXP > NTAPS ? MAXP : NTAPS); q < qlim; q += NW) issue_piece(Ti, piece_off(Ti, q, 0), sin, sw, nbuf, q);   // MODE 0 / 2
 #if FNET_CONV_STAMPS
             STAMP(st_a);
             st_loop += st_a - st_b;
@@ -390,8 +399,6 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_conv3x3_dma(const 
 #endif
         if (!have_next) break;
         cur = nxt;
-#pragma unroll
-        for (int k = 0; k < S2_MAXP; ++k) so_cur[k] = so_nxt[k];
     }
 #if FNET_CONV_STAMPS
     if (tid == 0 && stamps) {

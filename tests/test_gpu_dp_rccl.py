@@ -58,7 +58,11 @@ CHILD = textwrap.dedent('''
 
 
 def test_bucketed_exchange_through_rccl_single_rank():
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import socket
+    with socket.socket() as sk:                 # a free rendezvous port on this host
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     r = subprocess.run([sys.executable, "-c", "ROOT = %r\n" % ROOT + CHILD], env=env, capture_output=True, text=True, timeout=240)
     print(r.stdout[-1500:])
     assert r.returncode == 0 and "RCCL-1RANK OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]

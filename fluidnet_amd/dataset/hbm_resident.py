@@ -85,6 +85,12 @@ class HbmBatchLoader:
         dev = store.frames.device
         self._idx = torch.zeros(batch_size, dtype=torch.int32, device=dev)
         self._flip = torch.zeros(batch_size, dtype=torch.int32, device=dev)
+        # Host staging for the per-batch indices and flip flags: two PINNED slots used in turn, each guarded by an event recorded behind
+        # its upload.  (An asynchronous copy from a pageable temporary may still be reading it after the temporary is gone; a blocking copy
+        # would stall the host behind the previous step's kernels.)
+        self._host = torch.zeros(2, 2, batch_size, dtype=torch.int32).pin_memory() if dev.type == "cuda" else torch.zeros(2, 2, batch_size, dtype=torch.int32)
+        self._host_ev = [None, None]
+        self._slot = 0
 
     def set_epoch(self, epoch: int) -> None:
         self.epoch = epoch
@@ -125,9 +131,18 @@ class HbmBatchLoader:
         o["p"][:6] = [st.frames.data_ptr(), self._idx.data_ptr(), self._flip.data_ptr(), x0.data_ptr(), y.data_ptr(), masks.data_ptr()]
         # the index / flag uploads and the kernel go to ONE stream (the reused index buffers would otherwise race)
         ctx = torch.cuda.stream(torch.cuda.ExternalStream(stream)) if stream is not None else contextlib.nullcontext()
+        slot = self._slot
+        self._slot ^= 1
+        if self._host_ev[slot] is not None:
+            self._host_ev[slot].synchronize()          # the upload that last used this slot (two gathers ago) has been consumed
+        self._host[slot, 0, :B].copy_(torch.from_numpy(st.frame_index(rows)))
+        self._host[slot, 1, :B].copy_(torch.from_numpy(np.ascontiguousarray(flips, dtype=np.int32)))
         with ctx:
-            self._idx[:B].copy_(torch.from_numpy(st.frame_index(rows)), non_blocking=True)
-            self._flip[:B].copy_(torch.from_numpy(np.ascontiguousarray(flips, dtype=np.int32)), non_blocking=True)
+            self._idx[:B].copy_(self._host[slot, 0, :B], non_blocking=True)
+            self._flip[:B].copy_(self._host[slot, 1, :B], non_blocking=True)
+            if self._idx.is_cuda:
+                self._host_ev[slot] = torch.cuda.Event()
+                self._host_ev[slot].record()
             rt.run_ops(ops, stream)
 
     def __iter__(self) -> Iterator[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]]:

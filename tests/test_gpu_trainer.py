@@ -174,10 +174,56 @@ def test_hbm_loader_epoch_equals_dataloader_epoch(tmp_path):
     assert len(host_batches) == len(loader) >= 2
     for k in out["host"][0]:      # later steps see weights that differ by the rounding noise of the atomics-based backward
         assert abs(out["hbm"][0][k] - out["host"][0][k]) <= 2e-4 * max(1.0, abs(out["host"][0][k])), k
-    # Adam turns a noise-level gradient element (rounding of the atomics-based backward) into a full +-lr step, so two correct
-    # runs can drift by lr per step in such elements; anything systematic (a wrong sample, flip or mask) moves every weight
+    # Two correct runs of this epoch do not stay together element by element (measured with tools/dbg_hbm_steps.py and
+    # tools/dbg_bias_sens.py, host batches against host batches): conv biases in front of InstanceNorm have a zero true gradient, so
+    # Adam turns their rounding noise into +-lr moves; the network is invariant to them only up to fp32 rounding (1e-6 relative), and in
+    # step 2 of this data one head output sits at z = +-4e-6 around the lower clamp bound of linear_clamp, whose gradient mask
+    # (torch.clamp passes the gradient only inside the bounds) then falls either way: a 4.5e-4 relative change of the gradient that
+    # Adam grows to > 1e-4 in about a fifth of the weights by the end of the epoch.  So the epoch-level bars are the drift bound of
+    # lr per step and a median; the step-level agreement is the lock-step test below.
     diff = (out["hbm"][1] - out["host"][1]).abs()
-    assert diff.max() <= 1.05e-3 * len(loader) and float((diff > 1e-4).float().mean()) < 0.05
+    print(f"[hbm vs host epoch] max param diff {float(diff.max()):.2e}, median {float(diff.median()):.2e}, fraction > 1e-4: {float((diff > 1e-4).float().mean()):.3f}")
+    assert diff.max() <= 1.05e-3 * len(loader) and float(diff.median()) < 1e-4 and float((diff > 1e-4).float().mean()) < 0.5
+
+
+def test_hbm_loader_steps_equal_dataloader_steps_from_the_same_state(tmp_path):
+    """Lock step: before every batch the host-fed trainer takes over the HBM-fed trainer's parameters and Adam moments; the plan
+    inputs written by the gather kernel then equal the host batch bit for bit, and loss terms and the whole gradient agree to the
+    run-to-run floor of the atomics-based backward (4e-7 of the largest element measured; bar 1e-5)."""
+    from fluidnet_amd.dataset.hbm_resident import HbmBatchLoader, HbmSequenceStore
+    root = _npz(tmp_path)
+    cfgT = _config(tmp_path, 2)
+    ds = FluidNPZSequenceDataset(root, "train", rollout_steps=2, preload=True, stride=1)
+    loader = HbmBatchLoader(HbmSequenceStore(ds), 2, shuffle=True, seed=3)
+    trs = []
+    for _ in range(2):
+        model, _ = _model()
+        trs.append(Trainer(model, loader, [], cfgT, "cuda", engine="plan"))
+    th, tc = trs
+    st = loader.store
+    ph = th._plan_for(loader.B, st.H, st.W, loader.K, loader.Km)
+    worst = 0.0
+    for rows, flips in loader.batches():
+        samples = [ds[int(i)] for i in rows]
+        hb = [torch.stack([s[j] for s in samples]).cuda() for j in range(3)]
+        for f, x in zip(flips, hb[0]):
+            assert not f and x.shape == (6, st.H, st.W)            # no augmentation in this loader: the host batch is the plain sample
+        tc.model.flat_params.copy_(th.model.flat_params)
+        for a, b in zip(tc.optimizer._state()[2:4], th.optimizer._state()[2:4]):
+            a.copy_(b)
+        loader.gather(rows, flips, ph.x0.tensor, ph.y.tensor, ph.masks.tensor)
+        dh = th._run_plan(ph)
+        dc = tc._native_step(*hb)
+        pc = tc._plan_for(loader.B, st.H, st.W, loader.K, loader.Km)
+        for name in ("x0", "y", "masks"):
+            assert torch.equal(getattr(ph, name).tensor, getattr(pc, name).tensor), name
+        for k in dc:
+            assert abs(dh[k] - dc[k]) <= 1e-6 * max(1.0, abs(dc[k])), (k, dh[k], dc[k])
+        gh, gc = th.model.flat_grads, tc.model.flat_grads
+        rel = float((gh - gc).abs().max() / gc.abs().max())
+        worst = max(worst, rel)
+        assert rel <= 1e-5, rel
+    print(f"[hbm vs host lock step] worst gradient difference {worst:.2e} of the largest element over {len(loader)} steps")
 
 
 def test_curriculum_k1_then_k2_with_warm_start(tmp_path):

@@ -49,7 +49,8 @@ CHILD = textwrap.dedent('''
     floor = rel(g2, g0)                   # two identical runs: the weight-gradient reduction and the norm sums end in float atomics
     gd = rel(g1, g0)
     print("RCCL-1RANK loss", l1, l0, "grad rel-L2 diff", gd, "(two identical runs:", floor, ") norms", n1, n0, "param max abs diff", float((p1 - p0).abs().max()))
-    assert l1 == l0 and abs(n1 - n0) < 1e-4 * n0 and gd < max(1e-4, 10 * floor), (l1, l0, n1, n0, gd, floor)
+    nfloor = abs(n2 - n0) / n0            # the clip norm of two identical runs moves with that noise too (1.4e-4 seen)
+    assert l1 == l0 and abs(n1 - n0) < max(1e-3, 10 * nfloor) * n0 and gd < max(1e-4, 10 * floor), (l1, l0, n1, n0, gd, floor, nfloor)
     # one Adam step: every element moves by at most lr whatever its gradient, so rounding-level gradient noise is bounded by 2 lr
     assert float((p1 - p0).abs().max()) <= 2e-3 * 1.01
     dist.destroy_process_group()

@@ -444,6 +444,39 @@ constexpr int WG_PX = 64;                 // pixels per chunk
 constexpr int WG_SROWS = 144;             // source rows staged per panel (>= (CH+2)*(CW+2))
 constexpr int WG_SROWS_S2 = 112;          // ... in the 2x2 (stride-2) form (>= (CH+1)*(CW+1))
 constexpr int WG_PART = 9 * 32 * 32;      // floats per wave partial
+#ifndef FNET_WG_STAGES
+#define FNET_WG_STAGES 3
+#endif
+constexpr int WG_STAGES = FNET_WG_STAGES; // LDS stage buffers (2 or 3)
+static_assert(WG_STAGES >= 2 && WG_STAGES <= 4, "two to four stage buffers");
+
+// LDS-DMA of 16 B per lane (64 lanes -> 1 KB landing linearly at `lds`) issued from inline assembly, so that hipcc does not know of it:
+// ds_read_b64_tr_b16 has no memory operand the waitcnt pass could prove disjoint from the DMA's destination, and with the builtin form
+// hipcc put `s_waitcnt vmcnt(0)` in front of the first fragment read after every DMA issue -- each chunk waited for the NEXT chunk's DMA
+// to land before it computed (no overlap inside a block; found in round 2 from the ISA).  The kernel orders DMA and reads itself:
+// wait_vmcnt<N>() + s_barrier before a stage buffer is read.  (hipcc's own vmcnt bookkeeping stays safe: operations it does not
+// know of only make its waits stricter.)
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+__device__ __forceinline__ i32x4 make_rsrc_words(const void* p, int bytes) {
+    const unsigned long long a = (unsigned long long)p;
+    i32x4 r;                                            // wave-uniform by construction; readfirstlane keeps it in SGPRs for the asm operand
+    r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)(a & 0xffffffffull));
+    r[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)((a >> 32) & 0xffffull));     // stride 0
+    r[2] = __builtin_amdgcn_readfirstlane(bytes);      // num_records (bytes: raw buffer)
+    r[3] = 0x00020000;
+    return r;
+}
+__device__ __forceinline__ void dma16_untracked(i32x4 rsrc, const unsigned char* lds, int voff) {
+    const unsigned m0v = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(lds_void_t*)lds);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(m0v), "v"(voff), "s"(rsrc) : "memory");
+}
+
+// s_waitcnt vmcnt(N) alone (gfx9 encoding: vmcnt = simm16[15:14]:[3:0], expcnt [6:4] and lgkmcnt [11:8] left at their maxima)
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+    __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14));
+}
 
 // one stage of DMA for chunk c into LDS buffer `buf` (see k_wgrad_dma)
 template <int NCO, int NCI, int PPW, bool S2>
@@ -465,8 +498,8 @@ __device__ __forceinline__ void wg_issue(unsigned char* smem, const bf16_t* __re
     // S2: the source is the full-resolution P-tensor ((2H+2) x (2W+2)) read as its space-to-depth view (see k_conv3x3_dma, MODE 1)
     const int Hps = S2 ? 2 * H + 2 : Hp, Wps = S2 ? 2 * W + 2 : Wp;
     const size_t simg = (size_t)n * Hps * Wps;
-    const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc((void*)(dout + img * ldc_do), 0, Hp * Wp * ldc_do * 2, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rss = __builtin_amdgcn_make_buffer_rsrc((void*)(src + simg * ldc_in), 0, Hps * Wps * ldc_in * 2, 0x00020000);
+    const i32x4 rsd = make_rsrc_words(dout + img * ldc_do, Hp * Wp * ldc_do * 2);
+    const i32x4 rss = make_rsrc_words(src + simg * ldc_in, Hps * Wps * ldc_in * 2);
     const int dbase = (y0 * Wp + x0) * ldc_do * 2;
     const int sbase = S2 ? (2 * (y0 - 1) * Wps + 2 * (x0 - 1)) * ldc_in * 2 : ((y0 - 1) * Wp + x0 - 1) * ldc_in * 2;
     unsigned char* base = smem + buf * STAGE;
@@ -477,9 +510,9 @@ __device__ __forceinline__ void wg_issue(unsigned char* smem, const bf16_t* __re
             const int cy = p_cyx[i] & 0xff, cx = p_cyx[i] >> 8;
             const bool ok = (y0 + cy <= H) && (x0 + cx <= W);
             const int off = ok ? p_off[i] + dbase : 0x7ffffff0;          // out of range -> the DMA writes zeros
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsd, (lds_void_t*)(base + p_lds[i]), 16, off, 0, 0, 0);
+            dma16_untracked(rsd, base + p_lds[i], off);
         } else if (pid < NP) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rss, (lds_void_t*)(base + p_lds[i]), 16, p_off[i] + sbase, 0, 0, 0);
+            dma16_untracked(rss, base + p_lds[i], p_off[i] + sbase);
         }
     }
 }
@@ -549,11 +582,28 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_dma(const bf16_t* __restrict__
 
     const int c_begin = blockIdx.x * chunks_per_block;
     const int c_end = min(nchunks, c_begin + chunks_per_block);
-    if (c_begin < c_end) wg_issue<NCO, NCI, PPW, S2>(smem, src, dout, c_begin, 0, wave, H, W, ldc_in, ldc_do, log2cw, cpi, ncx, p_off, p_lds, p_cyx);
+    // WG_STAGES stage buffers, the DMA runs WG_STAGES - 1 chunks ahead: with one block per CU a single stage in flight (27 KB per CU, 7 MB
+    // chip-wide) left the kernel latency-bound (solo: 512 blocks 19 % faster than 256).  A chunk has landed when this wave's DMA count is
+    // down to the pieces of the chunks issued after it (vmcnt counts in order; the loop issues no other vector memory operation) and
+    // every wave has passed the barrier; the buffer refilled in iteration c was last read in iteration c - 1, before that barrier.
+    const int npw = (NP - 1 - wave) / 4 + 1;             // pieces this wave issues per chunk: PPW or PPW - 1
+#pragma unroll
+    for (int k = 0; k < WG_STAGES - 1; ++k)
+        if (c_begin + k < c_end) wg_issue<NCO, NCI, PPW, S2>(smem, src, dout, c_begin + k, k, wave, H, W, ldc_in, ldc_do, log2cw, cpi, ncx, p_off, p_lds, p_cyx);
+    int cur = 0;
     for (int c = c_begin; c < c_end; ++c) {
-        __syncthreads();
-        const int cur = (c - c_begin) & 1;
-        if (c + 1 < c_end) wg_issue<NCO, NCI, PPW, S2>(smem, src, dout, c + 1, cur ^ 1, wave, H, W, ldc_in, ldc_do, log2cw, cpi, ncx, p_off, p_lds, p_cyx);
+        const int ahead = min(c_end - 1 - c, WG_STAGES - 2);   // chunks issued after chunk c and still allowed in flight
+        if (ahead <= 0) wait_vmcnt<0>();
+        else if (ahead == 1) { if (npw == PPW) wait_vmcnt<PPW>(); else wait_vmcnt<PPW - 1>(); }
+        else { if (npw == PPW) wait_vmcnt<2 * PPW>(); else wait_vmcnt<2 * (PPW - 1)>(); }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        {
+            int nb = cur + WG_STAGES - 1;
+            nb = nb >= WG_STAGES ? nb - WG_STAGES : nb;
+            if (c + WG_STAGES - 1 < c_end)
+                wg_issue<NCO, NCI, PPW, S2>(smem, src, dout, c + WG_STAGES - 1, nb, wave, H, W, ldc_in, ldc_do, log2cw, cpi, ncx, p_off, p_lds, p_cyx);
+        }
         const unsigned char* pa = smem + cur * STAGE + cop * (WG_PX * PANEL_ROW);
         const unsigned char* pb = smem + cur * STAGE + DB + cip * (SROWS * PANEL_ROW);
 #pragma unroll
@@ -570,6 +620,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_dma(const bf16_t* __restrict__
                     acc[ty * TW + tx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[ty * TW + tx], 0, 0, 0);
                 }
         }
+        cur = cur + 1 == WG_STAGES ? 0 : cur + 1;
     }
     // KS > 1: the KS waves that split the k-steps of one panel pair add their accumulators up through LDS (lane-linear 36-KB images, one
     // per pair, over the stage buffers) before anything goes to the slab: KS times fewer partials to write and to reduce
@@ -784,7 +835,7 @@ int fnet_wgrad_mfma(const FnetOp& op, hipStream_t st) {
     const dim3 grid(splits, co_tiles, ci_tiles);
 #define WGD_LAUNCH2(A, B_, S2_)                                                                                                       \
     {                                                                                                                                \
-        size_t lds = 2 * ((size_t)A * WG_PX * PANEL_ROW + (size_t)B_ * (S2_ ? WG_SROWS_S2 : WG_SROWS) * PANEL_ROW);                   \
+        size_t lds = WG_STAGES * ((size_t)A * WG_PX * PANEL_ROW + (size_t)B_ * (S2_ ? WG_SROWS_S2 : WG_SROWS) * PANEL_ROW);           \
         if (A * B_ < 4 && lds < (size_t)A * B_ * WG_PART * 4) lds = (size_t)A * B_ * WG_PART * 4;                                     \
         int rc = set_lds_limit(k_wgrad_dma<A, B_, S2_>, lds);                                                                         \
         if (rc) return rc;                                                                                                           \

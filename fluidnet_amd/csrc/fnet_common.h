@@ -80,6 +80,36 @@ struct Vec8<bf16_t> {
     }
 };
 
+// Eight channels as loaded (still packed): the multi-pixel trips of the channel-group kernels issue the loads of all their pixels into
+// Raw8 registers, fence the instruction scheduler, and only then unpack.  With Vec8::load (load + unpack in one) hipcc hoisted the first
+// pixel's unpack in front of the later pixels' loads and put `s_waitcnt vmcnt(1)` there: a wave had 2 of its 6 loads in flight, then 4.
+template <typename T>
+struct Raw8;
+template <>
+struct Raw8<float> {
+    float4 a, b;
+    __device__ __forceinline__ void load(const float* p) {
+        a = *reinterpret_cast<const float4*>(p);
+        b = *reinterpret_cast<const float4*>(p + 4);
+    }
+    __device__ __forceinline__ void unpack(float (&v)[8]) const {
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    }
+};
+template <>
+struct Raw8<bf16_t> {
+    uint4 a;
+    __device__ __forceinline__ void load(const bf16_t* p) { a = *reinterpret_cast<const uint4*>(p); }
+    __device__ __forceinline__ void unpack(float (&v)[8]) const {
+        const uint32_t w[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            v[2 * k] = __uint_as_float(w[k] << 16);
+            v[2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u);
+        }
+    }
+};
+
 // 16-byte streaming store of an already packed vector (convolution epilogue)
 __device__ __forceinline__ void st_stream16(bf16_t* p, const uint4& v) {
 #if FNET_NT_STORE

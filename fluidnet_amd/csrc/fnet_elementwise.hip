@@ -366,7 +366,7 @@ __global__ __launch_bounds__(256) void k_apply(const T* __restrict__ raw, const 
     auto trip = [&](auto uc, auto rc) {
         constexpr int UU = decltype(uc)::value;
         constexpr bool RES = decltype(rc)::value != 0;
-        Vec8<T> r[UU], q[UU];
+        Raw8<T> r[UU], q[UU];
         uint32_t keep[UU];
 #pragma unroll
         for (int u = 0; u < UU; ++u) {
@@ -381,13 +381,17 @@ __global__ __launch_bounds__(256) void k_apply(const T* __restrict__ raw, const 
             if (RES) q[u].load(sbase + pix_off(sp, ldc_res));
             w.step();
         }
+        __builtin_amdgcn_sched_barrier(0);     // every load of the trip is out before the first unpack (see Raw8)
 #pragma unroll
         for (int u = 0; u < UU; ++u) {
             Vec8<T> o;
+            float rv[8], qv[8];
+            r[u].unpack(rv);
+            if (RES) q[u].unpack(qv);
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                float v = act_fwd_t<ACT>(fmaf(r[u].v[k], ca[k], cb[k])) * dsc[k];
-                if (RES) v += q[u].v[k];
+                float v = act_fwd_t<ACT>(fmaf(rv[k], ca[k], cb[k])) * dsc[k];
+                if (RES) v += qv[k];
                 o.v[k] = keep_bits(v, keep[u]);
             }
             o.store_nt(dbase + pix_off((uint32_t)(p + u * ps), ldc_dst));
@@ -480,20 +484,25 @@ __global__ __launch_bounds__(256) void k_inact_bwd_reduce(const T* __restrict__ 
         auto trip = [&](auto uc, auto gc) {
             constexpr int UU = decltype(uc)::value;
             constexpr bool G2 = decltype(gc)::value != 0;
-            Vec8<T> a1[UU], a2[UU], r[UU];
+            Raw8<T> ra1[UU], ra2[UU], rr[UU];
             uint32_t pix[UU];
             int yy[UU], xx[UU];
 #pragma unroll
             for (int u = 0; u < UU; ++u) {
                 yy[u] = w.y; xx[u] = w.x;
                 pix[u] = pix_of(w.y + 1, w.x + 1, Wp);
-                a1[u].load(g1img + pix_off(pix[u], ldc_g1));
-                if (G2) a2[u].load(g2img + pix_off(pix[u], ldc_g2));
-                r[u].load(rbase + pix_off(pix[u], ldc_raw));
+                ra1[u].load(g1img + pix_off(pix[u], ldc_g1));
+                if (G2) ra2[u].load(g2img + pix_off(pix[u], ldc_g2));
+                rr[u].load(rbase + pix_off(pix[u], ldc_raw));
                 w.step();
             }
+            __builtin_amdgcn_sched_barrier(0);     // every load of the trip is out before the first unpack (see Raw8)
+            Vec8<T> a1[UU], a2[UU], r[UU];
 #pragma unroll
             for (int u = 0; u < UU; ++u) {
+                ra1[u].unpack(a1[u].v);
+                if (G2) ra2[u].unpack(a2[u].v);
+                rr[u].unpack(r[u].v);
                 float acc[8];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) acc[k] = G2 ? a1[u].v[k] + a2[u].v[k] : a1[u].v[k];
@@ -594,7 +603,7 @@ __global__ __launch_bounds__(256) void k_inact_bwd_apply(const T* __restrict__ G
     const int fylo = pad_lo(H, pm), fyhi = pad_hi(H, pm), fxlo = pad_lo(W, pm), fxhi = pad_hi(W, pm);
     auto trip = [&](auto uc) {
         constexpr int UU = decltype(uc)::value;
-        Vec8<T> g[UU], r[UU];
+        Raw8<T> rg[UU], rr[UU];
         uint32_t keep[UU];
         int yy[UU], xx[UU];
 #pragma unroll
@@ -602,12 +611,16 @@ __global__ __launch_bounds__(256) void k_inact_bwd_apply(const T* __restrict__ G
             keep[u] = (w.y == 0 || w.y == Hp - 1 || w.x == 0 || w.x == Wp - 1) ? 0u : 0xffffffffu;   // ring: loaded all the same (valid memory), zeroed below
             yy[u] = w.y - 1; xx[u] = w.x - 1;
             const uint32_t pu = (uint32_t)(p + u * ps);
-            g[u].load(Gbase + pix_off(pu, ldc_G));
-            r[u].load(rbase + pix_off(pu, ldc_raw));
+            rg[u].load(Gbase + pix_off(pu, ldc_G));
+            rr[u].load(rbase + pix_off(pu, ldc_raw));
             w.step();
         }
+        __builtin_amdgcn_sched_barrier(0);     // every load of the trip is out before the first unpack (see Raw8)
+        Vec8<T> g[UU], r[UU];
 #pragma unroll
         for (int u = 0; u < UU; ++u) {
+            rg[u].unpack(g[u].v);
+            rr[u].unpack(r[u].v);
             if (do_fold && keep[u] && (yy[u] == fylo || yy[u] == fyhi || xx[u] == fxlo || xx[u] == fxhi)) {
                 fold_extras8<T>(Gbase, yy[u], xx[u], H, W, ldc_G, pm, g[u].v);
                 if (sizeof(T) == 2) {

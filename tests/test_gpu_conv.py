@@ -91,6 +91,23 @@ def test_big_tile_selected_at_full_size():
     assert not failures, "\n".join(failures)
 
 
+# Weight gradient with several 64-pixel chunks per block (the three-deep DMA pipeline: prologue of two chunks, steady state, drain) and a
+# ragged last block: chunks = B * ceil(W/32) * ceil(H/2) for W > 16, one block per CU (256) over the launch
+WG_PIPE_SHAPES = [
+    (20, 32, 32, 32, 32, 32, 0, 32, 0),      # 320 chunks -> 2 per block
+    (40, 32, 32, 64, 64, 64, 0, 64, 0),      # 640 chunks -> 3 per block, 214 blocks, the last with 1
+    (5, 128, 128, 32, 64, 32, 0, 64, 0),     # 1280 chunks -> 5 per block
+    (9, 64, 64, 64, 32, 128, 64, 32, 0),     # 576 chunks -> 3 per block; channel slice of a wider source
+]
+
+
+@pytest.mark.parametrize("shape", WG_PIPE_SHAPES, ids=[f"B{s[0]}_{s[1]}x{s[2]}_{s[3]}to{s[4]}" for s in WG_PIPE_SHAPES])
+def test_wgrad_multi_chunk_pipeline(shape):
+    pb, ops = _mk(*shape, "bf16", "mfma")
+    failures = lockstep(pb, ops[1:])
+    assert not failures, "\n".join(failures)
+
+
 S2_SHAPES = [
     # B, h,  w,  C (per phase), Cout, ldc_full, coff_full     (full-resolution image 2h x 2w)
     (2, 16, 16, 32, 32, 64, 32),        # the cat-buffer skip slice of the training plan

@@ -234,7 +234,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_conv3x3_dma(const 
 #if FNET_CONV_STAMPS
     // diagnostic build (tools/conv_bench.py): wave 0 of every block adds its cycles spent waiting at the stage barrier, in the
     // tap loops, in the epilogue and in total to the first 5 int64 of `stamps`
-    long long st_bar = 0, st_loop = 0, st_epi = 0, st_t0 = __builtin_amdgcn_s_memtime(), st_a, st_b;
+    long long st_bar0 = 0, st_bar = 0, st_loop = 0, st_epi = 0, st_t0 = __builtin_amdgcn_s_memtime(), st_a, st_b;
 #define STAMP(x) x = __builtin_amdgcn_s_memtime()
 #else
 #define STAMP(x)
@@ -256,6 +256,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_conv3x3_dma(const 
             STAMP(st_b);
 #if FNET_CONV_STAMPS
             st_bar += st_b - st_a;
+            if (s == 0) st_bar0 += st_b - st_a;
 #endif
             // The next stage's DMA (of this tile, or stage 0 of the block's next tile: it then lands during the epilogue) is
             // issued one piece per tap INSIDE the tap loop below: a piece costs the issuing wave 60-185 cycles, which hide behind
@@ -407,6 +408,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_conv3x3_dma(const 
         atomicAdd((unsigned long long*)stamps + 2, (unsigned long long)st_epi);
         atomicAdd((unsigned long long*)stamps + 3, (unsigned long long)(__builtin_amdgcn_s_memtime() - st_t0));
         atomicAdd((unsigned long long*)stamps + 4, 1ull);
+        atomicAdd((unsigned long long*)stamps + 5, (unsigned long long)st_bar0);
     }
 #endif
 #undef STAMP

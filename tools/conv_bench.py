@@ -76,7 +76,7 @@ def run(B=64, reps=20, layers=None):
                 torch.cuda.synchronize()
                 c = sc.tensor[:16].view(torch.int64).cpu().numpy()
                 nb = max(1, int(c[4]))
-                out.append("cycles/block barrier-wait %d taps %d epilogue %d total %d (blocks %d)" % (c[0] / nb, c[1] / nb, c[2] / nb, c[3] / nb, nb))
+                out.append("cycles/block barrier-wait %d (of which at a tile's first stage %d) taps %d epilogue %d total %d (blocks %d)" % (c[0] / nb, c[5] / nb, c[1] / nb, c[2] / nb, c[3] / nb, nb))
         print(f"B={B:3d} H={H:4d} {cin:4d}->{cout:4d}: " + " | ".join(out), flush=True)
 
 

@@ -52,7 +52,7 @@ typedef const __attribute__((address_space(1))) void gbl_void_t;
 // ahead, + 2*NT MFMAs.  MFMA orientation: A = weights (rows = cout), B = pixels, so D[cout][pixel] leaves 4 consecutive
 // couts of one pixel in each accumulator quad = one 8-B LDS store into the pixel-major output tile (XOR-swizzled
 // 16-B chunks, pitch TN*2), which then streams out 16 B per lane.
-// FNET_CONV_ABLATE (diagnostic builds only, tools/conv_bench.py): 1 = no MFMA, 2 = no DMA after the first stage
+// FNET_CONV_ABLATE (diagnostic builds only, tools/conv_bench.py): 1 = no MFMA, 2 = no DMA after the first stage, 3 = weight pieces only for the first two stages of a block (what LDS-resident weights would save at most)
 #ifndef FNET_CONV_ABLATE
 #define FNET_CONV_ABLATE 0
 #endif
@@ -199,10 +199,15 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_conv3x3_dma(const 
     // one DMA piece (1 KB = 32 rows x 32 B) of stage s of tile T into the stage buffer at byte offset boff: pieces [0, npi) are the
     // input run, [npi, npi + NPW) the weight slab; voff = the piece's per-lane offset (po[k], or piece_off for the rare pieces beyond
     // the register slots), sin / sw = the stage's scalar offsets
+    unsigned g = 0;                       // running stage counter: stage buffer = g & 1
     auto issue_piece = [&](const ConvTile& T, int voff, int sin, int sw, int boff, int q) {
         unsigned char* wdst = smem + boff;
         if (q < npi) __builtin_amdgcn_raw_ptr_buffer_load_lds(T.rs, (lds_void_t*)(wdst + WB + q * 1024), 16, voff, sin, 0, 0);
+#if FNET_CONV_ABLATE == 3
+        else if (g < 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_void_t*)(wdst + (q - npi) * 1024), 16, voff, sw, 0, 0);   // weights staged once per buffer
+#else
         else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_void_t*)(wdst + (q - npi) * 1024), 16, voff, sw, 0, 0);
+#endif
     };
 
     // fragment read addresses (bytes, relative to a stage buffer): taps x 2 pixel sub-tiles; weights: lane base + immediates
@@ -230,7 +235,6 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_conv3x3_dma(const 
     if (!have) return;
     piece_offsets(cur, po);
     int L = blockIdx.x;
-    unsigned g = 0;                       // running stage counter: stage buffer = g & 1
 #if FNET_CONV_STAMPS
     // diagnostic build (tools/conv_bench.py): wave 0 of every block adds its cycles spent waiting at the stage barrier, in the
     // tap loops, in the epilogue and in total to the first 5 int64 of `stamps`

@@ -215,6 +215,29 @@ def profile_ops(plan_arrays, recs_by_section, dump_path=None):
     return agg
 
 
+def reference_gemm():
+    """For reading `roofline.frac`: what the vendor-tuned dense bf16 GEMM (torch.matmul -> hipBLASLt) reaches on THIS box, on a large square
+    problem and on the plain-GEMM shape of the step's heaviest convolution class (M = pixels of 64 images of 130x130, N = 64 couts,
+    K = 9 * 64, no im2col cost counted).  Informational: `peak` stays the data-sheet figure."""
+    import torch
+    res = {}
+    for key, (m, n, k) in (("square_8192", (8192, 8192, 8192)), ("conv_64to64_128x128_shape", (1081600, 64, 576))):
+        a_ = torch.randn(m, k, device="cuda", dtype=torch.bfloat16)
+        b_ = torch.randn(k, n, device="cuda", dtype=torch.bfloat16)
+        for _ in range(3):
+            c_ = a_ @ b_
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            c_ = a_ @ b_
+        e1.record()
+        torch.cuda.synchronize()
+        res[key + "_tflops"] = round(2.0 * m * n * k / (e0.elapsed_time(e1) / 10) / 1e9, 1)
+        del a_, b_, c_
+    res["kind"] = "torch.matmul bf16 (hipBLASLt), measured in this run"
+    return res
+
+
 def pmc_traffic(kernel):
     """Per-launch HBM bytes of `kernel` from the newest committed PMC summary (tools/pmc_traffic.py; rocprofv3 cannot run inside
     the timed process, so the counters come from a separate pass of the same workload), or None."""
@@ -404,6 +427,8 @@ def main():
                                "launches_per_step": conv["n"], "avg_launch_ms": round(conv["ms"] / conv["n"], 4),
                                "algorithmic_gflop_per_launch": round(conv["flops"] / conv["n"] / 1e9, 3),
                                "algorithmic_bytes_per_launch": round(conv["bytes"] / conv["n"])}
+            if default_wl:
+                out["roofline"]["reference_gemm"] = reference_gemm()
             out["breakdown_ms_per_step"] = {k: round(v["ms"], 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
             out["breakdown_ms_per_step"]["_sum"] = round(tot, 3)
             wg = agg.get("WGRAD_MFMA")

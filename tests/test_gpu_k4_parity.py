@@ -14,7 +14,7 @@ for K = 1, 2, 4 (ml/training/trainer.py:348-385), in two regimes:
       trained K3 weights (ml/scripts/train.py:132-138) -- with the gradients taken on ANOTHER batch of the same distribution (on the
       training batch itself the K1 gradient sits at a minimum, norm 0.01, and its direction is rounding noise in any arithmetic).
       This is the stated bf16 tolerance of the training step:
-          loss within 2e-2 rel, final prediction rel-L2 <= 8e-2, whole-gradient cosine >= BAR_COS[K].
+          loss within 2e-2 rel, final prediction rel-L2 <= 8e-2, ||g16 - g32|| <= ERR_REL * ||g32|| + ERR_ABS and whole-gradient cosine >= BAR_COS.
 The numbers of the last run are written to gpurun_out/k4_parity.json (per-tensor cosines included).
 """
 import json
@@ -34,7 +34,15 @@ from helpers import unpack
 
 pytestmark = pytest.mark.gpu
 B, R = 4, 128
-BAR_COS = {1: 0.985, 2: 0.975, 4: 0.985}          # trained regime; see DESIGN.md section 5 for the measured values
+# Trained regime.  The 200-step warm-up is not bit-reproducible (fp32 atomics in the backward sums, amplified by Adam),
+# so the point the gradients are taken at differs from run to run: over six warm-ups (profiles/r2_k4_parity_spread.log) the held-out
+# gradient norm was 0.015 - 0.135 while the ABSOLUTE bf16 error stayed at 1.4e-3 - 4.5e-3 (~ 0.02 * norm + 1.7e-3: a noise floor that does
+# not shrink with the gradient), i.e. cosine 0.985 - 0.9995, lower where the warm-up happened to land closer to a stationary point.
+# The stated tolerance is therefore the error bound below plus the cosine bar VERDICT r1 named (0.95), the latter only where the gradient
+# is not itself at the noise floor.
+BAR_COS = 0.95
+ERR_REL, ERR_ABS = 0.06, 5e-3                     # ||g16 - g32|| <= ERR_REL * ||g32|| + ERR_ABS   (measured: at most 0.45 of this bound)
+GNORM_MIN = 0.01                                  # below this norm the direction of the held-out gradient is the noise floor's
 
 
 def _crit():
@@ -88,8 +96,7 @@ def batch():
     return synth_rollout_batch(B, 4, R, seed=4321)
 
 
-@pytest.fixture(scope="module")
-def trained(batch):
+def _warm_up(batch):
     """200 K1 Adam steps (lr 1e-3, clip 1.0) of the bf16 plan on the fixed batch, from the seeded initialisation."""
     m = _model("bf16")
     p = RolloutTrainPlan(m.cfg, _crit(), B, R, R, 1, dtype="bf16", weight_decay=1.10, clip_norm=1.0)
@@ -108,6 +115,11 @@ def trained(batch):
     print(f"[k4 parity] warm-up training: K1 loss {first:.5f} -> {last:.5f} after 200 steps")
     assert np.isfinite(last) and last < 0.5 * first
     return m.flat_params.detach().clone()
+
+
+@pytest.fixture(scope="module")
+def trained(batch):
+    return _warm_up(batch)
 
 
 _REPORT = {}
@@ -152,4 +164,7 @@ def test_bf16_vs_fp32_plan_after_training(trained, K):
           f"gradient cos {r['grad_cos']:.4f} rel-L2 {r['grad_rel']:.3f} norms {r['gnorm16']:.2f}/{r['gnorm32']:.2f}; worst tensor {r['worst_tensor']}")
     assert abs(r["loss16"] - r["loss32"]) < 2e-2 * abs(r["loss32"])
     assert r["pred_rel"][-1] < 8e-2
-    assert r["grad_cos"] > BAR_COS[K], r["grad_cos"]
+    err = r["grad_rel"] * r["gnorm32"]
+    assert err <= ERR_REL * r["gnorm32"] + ERR_ABS, (err, r["gnorm32"])
+    if r["gnorm32"] >= GNORM_MIN:
+        assert r["grad_cos"] > BAR_COS, r["grad_cos"]

@@ -446,15 +446,28 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* panel, int k0, in
 // registers for its whole pixel range and finally writes them, with plain coalesced stores, as one 36-KB partial into
 // the slab; k_wgrad_reduce adds the partials into dWk.  (Accumulating with float atomics instead ran at the chip-wide
 // atomic rate: ~140 MB of adds per launch at 1.3 TB/s was a third of the kernel.)
-constexpr int WG_PX = 64;                 // pixels per chunk
-constexpr int WG_SROWS = 144;             // source rows staged per panel (>= (CH+2)*(CW+2))
-constexpr int WG_SROWS_S2 = 112;          // ... in the 2x2 (stride-2) form (>= (CH+1)*(CW+1))
+// Pixels per chunk, PX: 64 (2 x 32 / 4 x 16) or 128 (4 x 32 / 8 x 16).  The kernel is bound by the bytes its LDS-DMA moves (ablation builds,
+// 64 -> 64 channels at 128^2: no MFMA 122 of 129 us, no DMA 97): a 64-pixel chunk stages a 144-pixel source halo per panel (2.25x), a
+// 128-pixel chunk 204 (1.6x) -- 20 % fewer staged bytes per pixel; the launcher takes 128 where the launch still has enough chunks.
+// source rows staged per panel: >= (CH+2)*(CW+2), in the 2x2 (stride-2) form >= (CH+1)*(CW+1), a multiple of 16
+__host__ __device__ constexpr int wg_srows(int px, bool s2) { return px == 64 ? (s2 ? 112 : 144) : (s2 ? 176 : 208); }
 constexpr int WG_PART = 9 * 32 * 32;      // floats per wave partial
 #ifndef FNET_WG_STAGES
 #define FNET_WG_STAGES 3
 #endif
 constexpr int WG_STAGES = FNET_WG_STAGES; // LDS stage buffers (2 or 3)
+// FNET_WG_ABLATE (diagnostic builds only, tools/conv_bench.py variants 11-13; results are wrong, only the time means something):
+// 1 = no MFMA, 2 = no DMA after a block's first chunks, 3 = no DMA wait / stage barrier
+#ifndef FNET_WG_ABLATE
+#define FNET_WG_ABLATE 0
+#endif
 static_assert(WG_STAGES >= 2 && WG_STAGES <= 4, "two to four stage buffers");
+// 128-pixel chunks run two stage buffers by default (85 KB, the LDS footprint of three 64-pixel stages: a convolution block of lane 0 still
+// fits beside the weight-gradient block on a CU; with three -- 129 KB -- the step was 0.3 ms slower although the kernel alone was faster)
+#ifndef FNET_WG_STAGES128
+#define FNET_WG_STAGES128 2
+#endif
+__host__ __device__ constexpr int wg_stages(int px) { return px == 64 ? WG_STAGES : FNET_WG_STAGES128; }
 
 // LDS-DMA of 16 B per lane (64 lanes -> 1 KB landing linearly at `lds`) issued from inline assembly, so that hipcc does not know of it:
 // ds_read_b64_tr_b16 has no memory operand the waitcnt pass could prove disjoint from the DMA's destination, and with the builtin form
@@ -472,8 +485,10 @@ __device__ __forceinline__ i32x4 make_rsrc_words(const void* p, int bytes) {
     r[3] = 0x00020000;
     return r;
 }
-__device__ __forceinline__ void dma16_untracked(i32x4 rsrc, const unsigned char* lds, int voff) {
-    const unsigned m0v = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(lds_void_t*)lds);
+// (`lds` = the destination's LDS byte address as an integer: a generic pointer cast back to the LDS address space here made hipcc emit a
+// null test against src_shared_base that failed its own machine verifier in one instantiation)
+__device__ __forceinline__ void dma16_untracked(i32x4 rsrc, unsigned lds, int voff) {
+    const unsigned m0v = (unsigned)__builtin_amdgcn_readfirstlane((int)lds);
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(m0v), "v"(voff), "s"(rsrc) : "memory");
 }
 
@@ -485,11 +500,11 @@ __device__ __forceinline__ void wait_vmcnt() {
 }
 
 // one stage of DMA for chunk c into LDS buffer `buf` (see k_wgrad_dma)
-template <int NCO, int NCI, int PPW, bool S2>
-__device__ __forceinline__ void wg_issue(unsigned char* smem, const bf16_t* __restrict__ src, const bf16_t* __restrict__ dout, int c, int buf,
+template <int NCO, int NCI, int PPW, bool S2, int WG_PX>
+__device__ __forceinline__ void wg_issue(unsigned smem_lds, const bf16_t* __restrict__ src, const bf16_t* __restrict__ dout, int c, int buf,
                                          int wave, int H, int W, int ldc_in, int ldc_do, int log2cw, int cpi, int ncx,
                                          const int (&p_off)[PPW], const int (&p_lds)[PPW], const int (&p_cyx)[PPW]) {
-    constexpr int SROWS = S2 ? WG_SROWS_S2 : WG_SROWS;
+    constexpr int SROWS = wg_srows(WG_PX, S2);
     constexpr int DB = NCO * WG_PX * PANEL_ROW;
     constexpr int SB = NCI * SROWS * PANEL_ROW;
     constexpr int STAGE = DB + SB;
@@ -508,7 +523,7 @@ __device__ __forceinline__ void wg_issue(unsigned char* smem, const bf16_t* __re
     const i32x4 rss = make_rsrc_words(src + simg * ldc_in, Hps * Wps * ldc_in * 2);
     const int dbase = (y0 * Wp + x0) * ldc_do * 2;
     const int sbase = S2 ? (2 * (y0 - 1) * Wps + 2 * (x0 - 1)) * ldc_in * 2 : ((y0 - 1) * Wp + x0 - 1) * ldc_in * 2;
-    unsigned char* base = smem + buf * STAGE;
+    const unsigned base = smem_lds + (unsigned)(buf * STAGE);
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
         const int pid = wave + 4 * i;
@@ -523,14 +538,15 @@ __device__ __forceinline__ void wg_issue(unsigned char* smem, const bf16_t* __re
     }
 }
 
-template <int NCO, int NCI, bool S2>
+template <int NCO, int NCI, bool S2, int WG_PX>
 __global__ __launch_bounds__(256, 2) void k_wgrad_dma(const bf16_t* __restrict__ src, const bf16_t* __restrict__ dout,
                                                       float* __restrict__ slab, int B, int H, int W, int ldc_in, int coff_in,
                                                       int ldc_do, int coff_do, int log2cw, int chunks_per_block, int nchunks,
                                                       int nparts, int n_ci_tiles, int Cs) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int KS = 4 / (NCO * NCI);       // waves that share one (co,ci) panel pair and split the k-steps
-    constexpr int SROWS = S2 ? WG_SROWS_S2 : WG_SROWS;
+    constexpr int NSTG = wg_stages(WG_PX);
+    constexpr int SROWS = wg_srows(WG_PX, S2);
     constexpr int DB = NCO * WG_PX * PANEL_ROW;      // dout bytes per stage
     constexpr int SB = NCI * SROWS * PANEL_ROW;      // source bytes per stage
     constexpr int STAGE = DB + SB;
@@ -588,27 +604,34 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_dma(const bf16_t* __restrict__
 
     const int c_begin = blockIdx.x * chunks_per_block;
     const int c_end = min(nchunks, c_begin + chunks_per_block);
-    // WG_STAGES stage buffers, the DMA runs WG_STAGES - 1 chunks ahead: with one block per CU a single stage in flight (27 KB per CU, 7 MB
+    // NSTG stage buffers, the DMA runs NSTG - 1 chunks ahead: with one block per CU a single stage in flight (27 KB per CU, 7 MB
     // chip-wide) left the kernel latency-bound (solo: 512 blocks 19 % faster than 256).  A chunk has landed when this wave's DMA count is
     // down to the pieces of the chunks issued after it (vmcnt counts in order; the loop issues no other vector memory operation) and
     // every wave has passed the barrier; the buffer refilled in iteration c was last read in iteration c - 1, before that barrier.
     const int npw = (NP - 1 - wave) / 4 + 1;             // pieces this wave issues per chunk: PPW or PPW - 1
+    const unsigned smem_lds = (unsigned)(size_t)(lds_void_t*)smem;      // LDS byte address of the dynamic array
 #pragma unroll
-    for (int k = 0; k < WG_STAGES - 1; ++k)
-        if (c_begin + k < c_end) wg_issue<NCO, NCI, PPW, S2>(smem, src, dout, c_begin + k, k, wave, H, W, ldc_in, ldc_do, log2cw, cpi, ncx, p_off, p_lds, p_cyx);
+    for (int k = 0; k < NSTG - 1; ++k)
+        if (c_begin + k < c_end) wg_issue<NCO, NCI, PPW, S2, WG_PX>(smem_lds, src, dout, c_begin + k, k, wave, H, W, ldc_in, ldc_do, log2cw, cpi, ncx, p_off, p_lds, p_cyx);
     int cur = 0;
     for (int c = c_begin; c < c_end; ++c) {
-        const int ahead = min(c_end - 1 - c, WG_STAGES - 2);   // chunks issued after chunk c and still allowed in flight
+        const int ahead = min(c_end - 1 - c, NSTG - 2);   // chunks issued after chunk c and still allowed in flight
+#if FNET_WG_ABLATE != 3
         if (ahead <= 0) wait_vmcnt<0>();
         else if (ahead == 1) { if (npw == PPW) wait_vmcnt<PPW>(); else wait_vmcnt<PPW - 1>(); }
         else { if (npw == PPW) wait_vmcnt<2 * PPW>(); else wait_vmcnt<2 * (PPW - 1)>(); }
         __builtin_amdgcn_s_barrier();
+#endif
         asm volatile("" ::: "memory");
         {
-            int nb = cur + WG_STAGES - 1;
-            nb = nb >= WG_STAGES ? nb - WG_STAGES : nb;
-            if (c + WG_STAGES - 1 < c_end)
-                wg_issue<NCO, NCI, PPW, S2>(smem, src, dout, c + WG_STAGES - 1, nb, wave, H, W, ldc_in, ldc_do, log2cw, cpi, ncx, p_off, p_lds, p_cyx);
+            int nb = cur + NSTG - 1;
+            nb = nb >= NSTG ? nb - NSTG : nb;
+#if FNET_WG_ABLATE == 2
+            if (false)
+#else
+            if (c + NSTG - 1 < c_end)
+#endif
+                wg_issue<NCO, NCI, PPW, S2, WG_PX>(smem_lds, src, dout, c + NSTG - 1, nb, wave, H, W, ldc_in, ldc_do, log2cw, cpi, ncx, p_off, p_lds, p_cyx);
         }
         const unsigned char* pa = smem + cur * STAGE + cop * (WG_PX * PANEL_ROW);
         const unsigned char* pb = smem + cur * STAGE + DB + cip * (SROWS * PANEL_ROW);
@@ -623,10 +646,14 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_dma(const bf16_t* __restrict__
 #pragma unroll
                 for (int tx = 0; tx < TW; ++tx) {
                     const bf16x8 b = tr_frag(pb, (cy + ty) * SW + cx0 + tx, lane);
+#if FNET_WG_ABLATE == 1
+                    asm volatile("" ::"v"(a), "v"(b));
+#else
                     acc[ty * TW + tx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[ty * TW + tx], 0, 0, 0);
+#endif
                 }
         }
-        cur = cur + 1 == WG_STAGES ? 0 : cur + 1;
+        cur = cur + 1 == NSTG ? 0 : cur + 1;
     }
     // KS > 1: the KS waves that split the k-steps of one panel pair add their accumulators up through LDS (lane-linear 36-KB images, one
     // per pair, over the stage buffers) before anything goes to the slab: KS times fewer partials to write and to reduce
@@ -822,12 +849,24 @@ int fnet_wgrad_mfma(const FnetOp& op, hipStream_t st) {
     }
     FNET_CHECK_ARG((op.p[0] % 16) == 0 && (op.p[1] % 16) == 0 && (op.p[3] % 16) == 0);
     const int log2cw = W > 16 ? 5 : 4;
-    const int CW = 1 << log2cw, CH = WG_PX / CW;
-    const int nch = B * ((W + CW - 1) / CW) * ((H + CH - 1) / CH);
+    const int CW = 1 << log2cw;
     const int co_tiles = (Cout + 32 * nco - 1) / (32 * nco), ci_tiles = (Cin + 32 * nci - 1) / (32 * nci);
     const int tiles = co_tiles * ci_tiles;
     // one block per CU over the whole launch: the launch shares the chip with lane 0 (r2 sweep: 256 -> 38.10 ms, 512 -> 38.4 ms per K4 step)
     static const int target_blocks = [] { const char* e = getenv("FNET_WG_BLOCKS"); return e ? atoi(e) : 256; }();
+    // 128-pixel chunks (20 % fewer staged bytes per pixel) where every block still gets >= 3 of them; FNET_WG_PX=64|128 forces one size
+    // (read at every launch, so that one test process can run both)
+    int px = 64;
+    {
+        const int ch128 = 128 / CW;
+        const long long nch128 = (long long)B * ((W + CW - 1) / CW) * ((H + ch128 - 1) / ch128);
+        const int want = (target_blocks + tiles - 1) / tiles;
+        if (nch128 >= 3ll * want) px = 128;
+        const char* e = getenv("FNET_WG_PX");
+        if (e) px = atoi(e) == 128 ? 128 : 64;
+    }
+    const int CH = px / CW;
+    const int nch = B * ((W + CW - 1) / CW) * ((H + CH - 1) / CH);
     int splits = (target_blocks + tiles - 1) / tiles;
     if (splits > nch) splits = nch;
     int cpb = (nch + splits - 1) / splits;
@@ -839,14 +878,18 @@ int fnet_wgrad_mfma(const FnetOp& op, hipStream_t st) {
     const bf16_t* dout = (const bf16_t*)op.p[1];
     float* slab = (float*)op.p[3];
     const dim3 grid(splits, co_tiles, ci_tiles);
+#define WGD_LAUNCH3(A, B_, S2_, PX_)                                                                                                  \
+    {                                                                                                                                \
+        size_t lds = wg_stages(PX_) * ((size_t)A * PX_ * PANEL_ROW + (size_t)B_ * wg_srows(PX_, S2_) * PANEL_ROW);                         \
+        if (A * B_ < 4 && lds < (size_t)A * B_ * WG_PART * 4) lds = (size_t)A * B_ * WG_PART * 4;                                     \
+        int rc = set_lds_limit(k_wgrad_dma<A, B_, S2_, PX_>, lds);                                                                    \
+        if (rc) return rc;                                                                                                           \
+        hipLaunchKernelGGL((k_wgrad_dma<A, B_, S2_, PX_>), grid, dim3(kThreads), lds, st, src, dout, slab, B, H, W, op.i[3], op.i[4], \
+                           op.i[6], op.i[7], log2cw, cpb, nch, nparts, ci_tiles, Cs);                                                \
+    }
 #define WGD_LAUNCH2(A, B_, S2_)                                                                                                       \
     {                                                                                                                                \
-        size_t lds = WG_STAGES * ((size_t)A * WG_PX * PANEL_ROW + (size_t)B_ * (S2_ ? WG_SROWS_S2 : WG_SROWS) * PANEL_ROW);           \
-        if (A * B_ < 4 && lds < (size_t)A * B_ * WG_PART * 4) lds = (size_t)A * B_ * WG_PART * 4;                                     \
-        int rc = set_lds_limit(k_wgrad_dma<A, B_, S2_>, lds);                                                                         \
-        if (rc) return rc;                                                                                                           \
-        hipLaunchKernelGGL((k_wgrad_dma<A, B_, S2_>), grid, dim3(kThreads), lds, st, src, dout, slab, B, H, W, op.i[3], op.i[4],      \
-                           op.i[6], op.i[7], log2cw, cpb, nch, nparts, ci_tiles, Cs);                                                \
+        if (px == 128) WGD_LAUNCH3(A, B_, S2_, 128) else WGD_LAUNCH3(A, B_, S2_, 64)                                                  \
     }
 #define WGD_LAUNCH(A, B_)                                                                                                            \
     {                                                                                                                                \
@@ -858,6 +901,7 @@ int fnet_wgrad_mfma(const FnetOp& op, hipStream_t st) {
     else WGD_LAUNCH(1, 1)
 #undef WGD_LAUNCH
 #undef WGD_LAUNCH2
+#undef WGD_LAUNCH3
     const int elems = ntaps * Cout * Cin;
     const int eb = (elems + kThreads - 1) / kThreads;
     static const int red_blocks = [] { const char* e = getenv("FNET_WG_RED_BLOCKS"); return e ? atoi(e) : 512; }();

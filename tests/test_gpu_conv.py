@@ -101,9 +101,35 @@ WG_PIPE_SHAPES = [
 ]
 
 
+@pytest.mark.parametrize("px", ["64", "128"])
 @pytest.mark.parametrize("shape", WG_PIPE_SHAPES, ids=[f"B{s[0]}_{s[1]}x{s[2]}_{s[3]}to{s[4]}" for s in WG_PIPE_SHAPES])
-def test_wgrad_multi_chunk_pipeline(shape):
+def test_wgrad_multi_chunk_pipeline(shape, px, monkeypatch):
+    # both chunk sizes of k_wgrad_dma (64 and 128 pixels; the launcher reads FNET_WG_PX at every launch)
+    monkeypatch.setenv("FNET_WG_PX", px)
     pb, ops = _mk(*shape, "bf16", "mfma")
+    failures = lockstep(pb, ops[1:])
+    assert not failures, "\n".join(failures)
+
+
+@pytest.mark.parametrize("px", ["64", "128"])
+def test_wgrad_chunk_sizes_on_every_shape(px, monkeypatch):
+    """The weight gradient of every shape above (ragged images, channel slices, W <= 16 and W > 16 chunk shapes, the 2x2 stride-2 form)
+    with the chunk size forced, whatever the launcher would pick by itself."""
+    monkeypatch.setenv("FNET_WG_PX", px)
+    for shape in SHAPES:
+        pb, ops = _mk(*shape, "bf16", "mfma")
+        failures = lockstep(pb, ops[1:])
+        assert not failures, f"{shape}: " + "\n".join(failures)
+    for shape in S2_SHAPES:
+        pb, ops = _mk_s2(*shape)
+        failures = lockstep(pb, ops[2:])
+        assert not failures, f"s2 {shape}: " + "\n".join(failures)
+
+
+def test_wgrad_128_pixel_chunks_selected_at_full_size():
+    # 16 images of 128x128, 64 -> 64 channels: 2048 chunks of 128 pixels >= 3 per block, so the launcher takes the 128-pixel form itself
+    assert "FNET_WG_PX" not in os.environ
+    pb, ops = _mk(16, 128, 128, 64, 64, 64, 0, 64, 0, "bf16", "mfma")
     failures = lockstep(pb, ops[1:])
     assert not failures, "\n".join(failures)
 

@@ -1,6 +1,9 @@
 """Native rollout C ABI (fnet_rollout_*, no torch on its path) against the Python-built RolloutInferPlan on the same weights:
 both hosts emit the same op records, so the states must agree bit for bit; plus the viewer's impulse contract and argument
-checking.  The Python plan itself is checked against the oracle in tests/test_gpu_api.py / test_gpu_lockstep.py."""
+checking.  The Python plan itself is checked against the oracle in tests/test_gpu_api.py / test_gpu_lockstep.py; the native library is
+also compared with the oracle directly (the G8 fixture's geometry and masks, every frame from the library's own previous state)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -71,6 +74,34 @@ def test_native_rollout_equals_python_plan(name, cfg, B, R):
     nat.step(1)
     assert np.array_equal(nat.read_state(), plan.step(1).cpu().numpy())
     nat.close()
+
+
+def test_native_rollout_against_oracle_on_g8_geometry(golden_dir):
+    """ml/scripts/simple_infer.py:226-260 through the C ABI alone: masks of the G8 fixture, zero initial state, 16 frames; frame f against
+    the oracle's UNet applied to the library's own state of frames f-1 / f-2 (bf16 bar of DESIGN.md section 5: rel-L2 <= 8e-2)."""
+    g = np.load(os.path.join(golden_dir, "g8_rollout16.npz"))
+    cfg = tiny_cfg(base_channels=16)             # the MFMA kernels need >= 16 channels (the fixture's own net has 8)
+    params, _ = _weights(cfg, seed=23)
+    model = UNet(UNetConfig(**cfg.__dict__), precision="bf16")
+    model.load_state_dict(params)
+    flat = checkpoint_floats(model.state_dict())
+    em, co = g["emitter"].astype(np.float32), g["collider"].astype(np.float32)
+    nat = NativeRollout(model.cfg, flat, 1, 32, 32)
+    nat.set_masks(em[None], co[None])
+    nat.set_state(None, None)
+    e, c = torch.from_numpy(em)[None, None], torch.from_numpy(co)[None, None]
+    cur, prev = torch.zeros(1, 3, 32, 32), torch.zeros(1, 1, 32, 32)
+    worst = 0.0
+    with torch.no_grad():
+        for f in range(16):
+            nat.step(1)
+            got = torch.from_numpy(nat.read_state())
+            ref = orc.unet_forward(params, cfg, torch.cat([cur, prev, e, c], 1), training=False)
+            worst = max(worst, float((got - ref).norm() / (ref.norm() + 1e-12)))
+            prev, cur = cur[:, 0:1], got
+    nat.close()
+    print(f"[native rollout vs oracle] 16 frames, worst rel-L2 {worst:.3e}")
+    assert np.isfinite(worst) and worst < 8e-2
 
 
 def test_native_rollout_rejects_bad_arguments():

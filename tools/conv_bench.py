@@ -25,7 +25,8 @@ def build():
         d = os.path.join(b.LIBDIR, f"abl{v}")
         os.makedirs(d, exist_ok=True)
         obj = os.path.join(d, "fnet_conv_mfma.o")
-        flag = "-DFNET_CONV_STAMPS=1" if v == 9 else f"-DFNET_CONV_ABLATE={v}"       # variant 9 = in-kernel cycle stamps
+        # variant 9 = in-kernel cycle stamps of the convolution; 11-13 = weight-gradient ablations (FNET_WG_ABLATE 1-3)
+        flag = "-DFNET_CONV_STAMPS=1" if v == 9 else (f"-DFNET_WG_ABLATE={v - 10}" if v > 10 else f"-DFNET_CONV_ABLATE={v}")
         subprocess.run([b._hipcc(), *b.FLAGS, flag, "-c", os.path.join(b.CSRC, "fnet_conv_mfma.hip"), "-o", obj], check=True)
         objs = [obj if s == "fnet_conv_mfma.hip" else os.path.join(b.LIBDIR, s.replace(".hip", ".o")) for s in b.SOURCES]
         subprocess.run([b._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", os.path.join(d, "libfluidnet_hip.so"), *objs], check=True)

@@ -848,8 +848,8 @@ int fnet_wgrad_mfma(const FnetOp& op, hipStream_t st) {
         FNET_CHECK_ARG(op.i[4] + Cin <= op.i[3] && (long long)(H + 2) * Wp * op.i[3] * 2 < (1ll << 31));
     }
     FNET_CHECK_ARG((op.p[0] % 16) == 0 && (op.p[1] % 16) == 0 && (op.p[3] % 16) == 0);
-    const int log2cw = W > 16 ? 5 : 4;
-    const int CW = 1 << log2cw;
+    int log2cw = W > 16 ? 5 : 4;
+    int CW = 1 << log2cw;
     const int co_tiles = (Cout + 32 * nco - 1) / (32 * nco), ci_tiles = (Cin + 32 * nci - 1) / (32 * nci);
     const int tiles = co_tiles * ci_tiles;
     // one block per CU over the whole launch: the launch shares the chip with lane 0 (r2 sweep: 256 -> 38.10 ms, 512 -> 38.4 ms per K4 step)
@@ -858,12 +858,14 @@ int fnet_wgrad_mfma(const FnetOp& op, hipStream_t st) {
     // (read at every launch, so that one test process can run both)
     int px = 64;
     {
-        const int ch128 = 128 / CW;
-        const long long nch128 = (long long)B * ((W + CW - 1) / CW) * ((H + ch128 - 1) / ch128);
+        const long long nch128 = (long long)B * ((W + 15) / 16) * ((H + 7) / 8);          // 8 x 16 chunks, see below
         const int want = (target_blocks + tiles - 1) / tiles;
         if (nch128 >= 3ll * want) px = 128;
         const char* e = getenv("FNET_WG_PX");
         if (e) px = atoi(e) == 128 ? 128 : 64;
+        // 128-pixel chunks are 8 rows x 16 columns at any image width: 180 source pixels per panel (1.41x) against 204 (1.59x) for 4 x 32
+        // -- a pixel's 32 channels are one 64-B DMA segment whatever the chunk shape
+        if (px == 128) { log2cw = 4; CW = 16; }
     }
     const int CH = px / CW;
     const int nch = B * ((W + CW - 1) / CW) * ((H + CH - 1) / CH);

@@ -62,3 +62,14 @@ for k in solo:
         a[0] += s_ * len(ovl[k]); a[1] += o_ * len(ovl[k]); a[2] += len(ovl[k])
 for n, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     print("  %-48s alone %7.1f us  overlapped %7.1f us  x%.2f  (%d launches)" % (n[:48], a[0] / a[2] / 1e3, a[1] / a[2] / 1e3, a[1] / a[0], a[2]))
+# idle gaps of the main queue (> 15 us): where lane 0 waits -- for a join with the side lane, or for the host
+mrows = sorted([(a, b, n) for (a, b, q, n, g) in rows if q == main_q])
+gaps = []
+for (a0, b0, n0), (a1, b1, n1) in zip(mrows, mrows[1:]):
+    if a1 - b0 > 15000:
+        side_busy = overlap(b0, a1, side)
+        gaps.append((a1 - b0, (b0 - t0) / 1e6, n0, n1, side_busy))
+print("main-queue idle gaps > 15 us: %d, together %.2f ms (all gaps together %.2f ms)" % (
+    len(gaps), sum(g[0] for g in gaps) / 1e6, sum(max(0, a1 - b0) for (a0, b0, n0), (a1, b1, n1) in zip(mrows, mrows[1:])) / 1e6))
+for g in sorted(gaps, reverse=True)[:14]:
+    print("  %7.1f us at %6.2f ms  after %-40s before %-40s side busy %5.1f us" % (g[0] / 1e3, g[1], g[2][:40], g[3][:40], g[4] / 1e3))

@@ -796,7 +796,12 @@ int fnet_conv3x3_mfma(const FnetOp& op, hipStream_t st) {
     const int n_mtiles = (Npix + tm - 1) / tm, n_ntiles = (Cout + TN - 1) / TN;
     const int n_items = 8 * ((n_mtiles + 7) / 8) * n_ntiles;
     // persistent grid: one (big) or two (small; LDS allows 2 at <= 80 KB each) blocks per CU, a multiple of 8 for the XCD mapping
-    int nblk = ((!big && lds <= 80 * 1024) ? 2 : 1) * cus;
+    // (the 256 x 32 tile -- 116-133 registers, <= 53 KB -- runs three blocks per CU: its layers have one or two 16-channel stages per tile,
+    // 18 MFMAs per wave and stage, far less than a DMA round trip, so what hides the latency is blocks in flight)
+    static const int bpc32 = [] { const char* e = getenv("FNET_CONV_BPC32"); return e ? atoi(e) : 3; }();
+    int bpc = (!big && lds <= 80 * 1024) ? 2 : 1;
+    if (!big && TN == 32 && bpc32 >= 3 && 3 * lds <= 160 * 1024) bpc = 3;
+    int nblk = bpc * cus;
     nblk = (nblk + 7) / 8 * 8;
     if (nblk > n_items) nblk = n_items;
     const dim3 grid(nblk);

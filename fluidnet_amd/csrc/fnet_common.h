@@ -306,6 +306,7 @@ FNET_DECL_OP(fnet_op_upsample2x_bwd);
 FNET_DECL_OP(fnet_op_unpack_grad);
 FNET_DECL_OP(fnet_op_zero);
 FNET_DECL_OP(fnet_op_prep_weights);
+int fnet_op_prep_weights_batch(const FnetOp* ops, int n, hipStream_t st, int* n_done);   // consecutive PREP_WEIGHTS records, one launch per 32
 FNET_DECL_OP(fnet_op_grad_norm);
 FNET_DECL_OP(fnet_op_adam);
 FNET_DECL_OP(fnet_op_copy_planes);

@@ -11,11 +11,10 @@ constexpr int kThreads = 256;
 // Channel counts that are not a multiple of 8 (UNet_small-medium's 20) run zero-padded: the padded rows / columns are zeros here, the
 // matching norm and bias parameters read as zeros from the flat buffer's alignment gaps, so padded channels carry exact zeros.
 template <typename T>
-__global__ __launch_bounds__(256) void k_prep_weights(const float* W, T* Wf, T* Wd, int Cout, int Cin, int Cin_pad, int Cout_d, int blocked,
-                                                      int Cout_pad, int Kd /* K dim of Wd: >= Cout_pad (the MFMA kernel walks K in 16s) */) {
+__device__ __forceinline__ void prep_elem(int idx, const float* W, T* Wf, T* Wd, int Cout, int Cin, int Cin_pad, int Cout_d, int blocked,
+                                          int Cout_pad, int Kd /* K dim of Wd: >= Cout_pad (the MFMA kernel walks K in 16s) */) {
     // logical layouts Wf[t][co][ci], Wd[t][ci][co] (flipped taps); "blocked" (MFMA convolution) stores the K axis in
     // 16-channel blocks outermost, [K/16][t][row][16], so that one LDS-DMA stage of the conv is a contiguous slab
-    const int idx = blockIdx.x * kThreads + threadIdx.x;
     const int nf = 9 * Cout_pad * Cin_pad;
     const int nd = Wd ? 9 * Cout_d * Kd : 0;
     if (idx < nf) {
@@ -29,13 +28,17 @@ __global__ __launch_bounds__(256) void k_prep_weights(const float* W, T* Wf, T* 
         st1<T>(Wd + o, (ci < Cin && co < Cout) ? W[((size_t)co * Cin + ci) * 9 + (8 - t)] : 0.f);
     }
 }
+template <typename T>
+__global__ __launch_bounds__(256) void k_prep_weights(const float* W, T* Wf, T* Wd, int Cout, int Cin, int Cin_pad, int Cout_d, int blocked,
+                                                      int Cout_pad, int Kd) {
+    prep_elem<T>(blockIdx.x * kThreads + threadIdx.x, W, Wf, Wd, Cout, Cin, Cin_pad, Cout_d, blocked, Cout_pad, Kd);
+}
 
 // nn.ConvTranspose2d(C, C, kernel_size=2, stride=2) (unet.py:150; weight [ci][co][a][b]) as a convolution with 4*Cout output channels
 // (phase q = 2a + b outermost) whose only non-zero tap is the centre one; DEPTH2SPACE then interleaves the phases:
 // Wf[4][q*Cout + co][ci] = W[ci][co][a][b], Wd[4][ci][q*Cout + co] = the same (the centre tap is its own flip).
 template <typename T>
-__global__ __launch_bounds__(256) void k_prep_weights_t2(const float* W, T* Wf, T* Wd, int Cout, int Cin, int Kf, int Cout_d, int blocked, int Kd) {
-    const int idx = blockIdx.x * kThreads + threadIdx.x;
+__device__ __forceinline__ void prep_elem_t2(int idx, const float* W, T* Wf, T* Wd, int Cout, int Cin, int Kf, int Cout_d, int blocked, int Kd) {
     const int R = 4 * Cout;
     const int nf = 9 * R * Kf;
     const int nd = Wd ? 9 * Cout_d * Kd : 0;
@@ -52,6 +55,10 @@ __global__ __launch_bounds__(256) void k_prep_weights_t2(const float* W, T* Wf, 
         st1<T>(Wd + o, (t == 4 && k < R && ci < Cin) ? W[((size_t)ci * Cout + co) * 4 + q] : 0.f);
     }
 }
+template <typename T>
+__global__ __launch_bounds__(256) void k_prep_weights_t2(const float* W, T* Wf, T* Wd, int Cout, int Cin, int Kf, int Cout_d, int blocked, int Kd) {
+    prep_elem_t2<T>(blockIdx.x * kThreads + threadIdx.x, W, Wf, Wd, Cout, Cin, Kf, Cout_d, blocked, Kd);
+}
 // dW[ci][co][a][b] (+)= dWk[4][q*Cout + co][ci]
 __global__ __launch_bounds__(256) void k_unprep_wgrad_t2(const float* dWk, float* dW, int Cout, int Cin, int Cin_w, int accumulate) {
     const int idx = blockIdx.x * kThreads + threadIdx.x;
@@ -65,8 +72,7 @@ __global__ __launch_bounds__(256) void k_unprep_wgrad_t2(const float* dWk, float
 // K index k = (py, px, c) = ph * C + c of the 4C axis, tap t' = (dy, dx) carries W[co][c][ky = 2dy + py][kx = 2dx + px] (0 if ky or kx = 3).
 //   Wf[4][Cout_pad][4C], K-blocked [4C/16][4][Cout_pad][16];  Wd[(ty,tx)][k][co] = Wf[(1-ty, 1-tx)][co][k], K-blocked [Kd/16][4][4C][16]
 template <typename T>
-__global__ __launch_bounds__(256) void k_prep_weights_s2(const float* W, T* Wf, T* Wd, int Cout, int C, int Cout_pad, int Kd) {
-    const int idx = blockIdx.x * kThreads + threadIdx.x;
+__device__ __forceinline__ void prep_elem_s2(int idx, const float* W, T* Wf, T* Wd, int Cout, int C, int Cout_pad, int Kd) {
     const int K = 4 * C;
     const int nf = 4 * Cout_pad * K;
     const int nd = Wd ? 4 * K * Kd : 0;
@@ -90,6 +96,36 @@ __global__ __launch_bounds__(256) void k_prep_weights_s2(const float* W, T* Wf, 
     const int ph = k / C, c = k - ph * C;
     const int ky = 2 * (t >> 1) + (ph >> 1), kx = 2 * (t & 1) + (ph & 1);
     st1<T>(out + o, (co < Cout && ky <= 2 && kx <= 2) ? W[((size_t)co * C + c) * 9 + ky * 3 + kx] : 0.f);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_prep_weights_s2(const float* W, T* Wf, T* Wd, int Cout, int C, int Cout_pad, int Kd) {
+    prep_elem_s2<T>(blockIdx.x * kThreads + threadIdx.x, W, Wf, Wd, Cout, C, Cout_pad, Kd);
+}
+
+// Several PREP_WEIGHTS records in one launch (the plan executor hands consecutive records over together: a training step re-lays
+// all ~30 weight tensors out before its first convolution, 4-13 us per launch with the chip idle in between).  Block b belongs to the
+// descriptor j with blk0[j] <= b < blk0[j + 1]; each element is produced by the same code as in the single-record kernels.
+constexpr int PREP_MAXB = 32;
+struct PrepDesc {
+    const float* W;
+    void* Wf;
+    void* Wd;
+    int Cout, Cin, a2, Cout_d, blocked, Cout_pad, Kd, kind;   // a2 = Cin_pad (kind 0) / Kf (kind 1); kind 2 uses Cout, Cin (= C), Cout_pad, Kd
+};
+struct PrepBatch {
+    PrepDesc d[PREP_MAXB];
+    int blk0[PREP_MAXB + 1];
+    int n;
+};
+template <typename T>
+__global__ __launch_bounds__(256) void k_prep_weights_multi(PrepBatch pb) {
+    int j = 0;
+    while (j + 1 < pb.n && (int)blockIdx.x >= pb.blk0[j + 1]) ++j;      // wave-uniform scan over <= 32 entries
+    const PrepDesc& d = pb.d[j];
+    const int idx = ((int)blockIdx.x - pb.blk0[j]) * kThreads + threadIdx.x;
+    if (d.kind == 1) prep_elem_t2<T>(idx, d.W, (T*)d.Wf, (T*)d.Wd, d.Cout, d.Cin, d.a2, d.Cout_d, d.blocked, d.Kd);
+    else if (d.kind == 2) prep_elem_s2<T>(idx, d.W, (T*)d.Wf, (T*)d.Wd, d.Cout, d.Cin, d.Cout_pad, d.Kd);
+    else prep_elem<T>(idx, d.W, (T*)d.Wf, (T*)d.Wd, d.Cout, d.Cin, d.a2, d.Cout_d, d.blocked, d.Cout_pad, d.Kd);
 }
 // dW[co][c][ky][kx] (+)= dWk[(ky>>1, kx>>1)][co][((ky&1), (kx&1), c)]
 __global__ __launch_bounds__(256) void k_unprep_wgrad_s2(const float* dWk, float* dW, int Cout, int C, int Cin_w, int accumulate, int Cout_pad) {
@@ -150,37 +186,81 @@ __global__ __launch_bounds__(256) void k_adam(float* p, const float* g, float* m
 //                  7 kind (0 conv3x3, 1 transposed 2x2 stride 2: see k_prep_weights_t2, 2 conv3x3 stride 2 in its 2x2 space-to-depth form:
 //                    see k_prep_weights_s2; Cin = C, Cin_pad = Cout_d = 4C, both layouts K-blocked)
 //               p: 0 W fp32 OIHW,1 Wf [9][Cout_pad][Cin_pad],2 Wd [9][Cout_d][Kd]|0
-int fnet_op_prep_weights(const FnetOp& op, hipStream_t st) {
+// validates one record and fills its descriptor and its element count (what the single-record launch and the batch both use)
+static int prep_describe(const FnetOp& op, PrepDesc* d, int* total) {
     const int Cout = op.i[0], Cin = op.i[1], Cin_pad = op.i[2], Cout_d = op.i[3], Cout_pad = op.i[5] ? op.i[5] : Cout;
+    FNET_CHECK_ARG(op.dtype == FNET_BF16 || op.dtype == FNET_F32);
+    *d = PrepDesc{(const float*)op.p[0], (void*)op.p[1], (void*)op.p[2], Cout, Cin, Cin_pad, Cout_d, op.i[4], Cout_pad, 0, op.i[7]};
     if (op.i[7] == 1) {
         // transposed 2x2 stride-2 convolution (i[7] = 1): W fp32 [Cin][Cout][2][2] -> Wf [9][4*Cout][Cin_pad], Wd [9][Cout_d][Kd], Kd >= 4*Cout
         const int Kd = op.i[6] ? op.i[6] : 4 * Cout;
         FNET_CHECK_ARG(Cout > 0 && Cin > 0 && Cin_pad >= Cin && op.p[0] && op.p[1] && (op.p[2] == 0 || (Cout_d >= Cin && Kd >= 4 * Cout)));
         FNET_CHECK_ARG(op.i[4] >= 0 && op.i[4] <= 3 && (!(op.i[4] & 1) || Cin_pad % 16 == 0) && (!(op.i[4] & 2) || Kd % 16 == 0));
-        const int total = 9 * 4 * Cout * Cin_pad + (op.p[2] ? 9 * Cout_d * Kd : 0);
-        DISPATCH_T(op.dtype, hipLaunchKernelGGL(k_prep_weights_t2<T>, dim3((total + kThreads - 1) / kThreads), dim3(kThreads), 0, st,
-                                                (const float*)op.p[0], (T*)op.p[1], (T*)op.p[2], Cout, Cin, Cin_pad, Cout_d, op.i[4], Kd));
-        FNET_LAUNCH_CHECK();
+        d->Kd = Kd;
+        *total = 9 * 4 * Cout * Cin_pad + (op.p[2] ? 9 * Cout_d * Kd : 0);
         return FNET_OK;
     }
     if (op.i[7] == 2) {
         const int Kd = op.i[6] ? op.i[6] : Cout_pad;
         FNET_CHECK_ARG(Cout > 0 && Cin >= 16 && Cin % 16 == 0 && Cin_pad == 4 * Cin && Cout_d == 4 * Cin && Cout_pad >= Cout && Kd >= Cout_pad);
         FNET_CHECK_ARG(op.i[4] == 3 && Kd % 16 == 0 && op.p[0] && op.p[1]);
-        const int total = 4 * Cout_pad * 4 * Cin + (op.p[2] ? 4 * 4 * Cin * Kd : 0);
-        DISPATCH_T(op.dtype, hipLaunchKernelGGL(k_prep_weights_s2<T>, dim3((total + kThreads - 1) / kThreads), dim3(kThreads), 0, st,
-                                                (const float*)op.p[0], (T*)op.p[1], (T*)op.p[2], Cout, Cin, Cout_pad, Kd));
-        FNET_LAUNCH_CHECK();
+        d->Kd = Kd;
+        *total = 4 * Cout_pad * 4 * Cin + (op.p[2] ? 4 * 4 * Cin * Kd : 0);
         return FNET_OK;
     }
     FNET_CHECK_ARG(op.i[7] == 0);
     FNET_CHECK_ARG(Cout > 0 && Cin > 0 && Cin_pad >= Cin && Cout_pad >= Cout && op.p[0] && op.p[1] && (op.p[2] == 0 || Cout_d >= Cin));
     const int Kd = op.i[6] ? op.i[6] : Cout_pad;
     FNET_CHECK_ARG(op.i[4] >= 0 && op.i[4] <= 3 && (!(op.i[4] & 1) || Cin_pad % 16 == 0) && (!(op.i[4] & 2) || Kd % 16 == 0) && Kd >= Cout_pad);
-    const int total = 9 * Cout_pad * Cin_pad + (op.p[2] ? 9 * Cout_d * Kd : 0);
-    DISPATCH_T(op.dtype, hipLaunchKernelGGL(k_prep_weights<T>, dim3((total + kThreads - 1) / kThreads), dim3(kThreads), 0, st,
-                                            (const float*)op.p[0], (T*)op.p[1], (T*)op.p[2], Cout, Cin, Cin_pad, Cout_d, op.i[4], Cout_pad, Kd));
+    d->Kd = Kd;
+    *total = 9 * Cout_pad * Cin_pad + (op.p[2] ? 9 * Cout_d * Kd : 0);
+    return FNET_OK;
+}
+
+int fnet_op_prep_weights(const FnetOp& op, hipStream_t st) {
+    PrepDesc d;
+    int total = 0;
+    const int rc = prep_describe(op, &d, &total);
+    if (rc != FNET_OK) return rc;
+    const dim3 grid((total + kThreads - 1) / kThreads);
+    if (d.kind == 1) {
+        DISPATCH_T(op.dtype, hipLaunchKernelGGL(k_prep_weights_t2<T>, grid, dim3(kThreads), 0, st, d.W, (T*)d.Wf, (T*)d.Wd, d.Cout, d.Cin, d.a2,
+                                                d.Cout_d, d.blocked, d.Kd));
+    } else if (d.kind == 2) {
+        DISPATCH_T(op.dtype, hipLaunchKernelGGL(k_prep_weights_s2<T>, grid, dim3(kThreads), 0, st, d.W, (T*)d.Wf, (T*)d.Wd, d.Cout, d.Cin, d.Cout_pad,
+                                                d.Kd));
+    } else {
+        DISPATCH_T(op.dtype, hipLaunchKernelGGL(k_prep_weights<T>, grid, dim3(kThreads), 0, st, d.W, (T*)d.Wf, (T*)d.Wd, d.Cout, d.Cin, d.a2,
+                                                d.Cout_d, d.blocked, d.Cout_pad, d.Kd));
+    }
     FNET_LAUNCH_CHECK();
+    return FNET_OK;
+}
+
+// n consecutive PREP_WEIGHTS records of one dtype in ceil(n / 32) launches.  Every record is validated like a single one; at the first
+// bad record the records before it are still launched (as fnet_plan_run would have) and *n_done says how many were.
+int fnet_op_prep_weights_batch(const FnetOp* ops, int n, hipStream_t st, int* n_done) {
+    *n_done = 0;
+    while (*n_done < n) {
+        PrepBatch pb;
+        pb.n = 0;
+        pb.blk0[0] = 0;
+        int rc = FNET_OK;
+        while (pb.n < PREP_MAXB && *n_done + pb.n < n) {
+            int total = 0;
+            rc = prep_describe(ops[*n_done + pb.n], &pb.d[pb.n], &total);
+            if (rc != FNET_OK) break;
+            pb.blk0[pb.n + 1] = pb.blk0[pb.n] + (total + kThreads - 1) / kThreads;
+            ++pb.n;
+        }
+        if (pb.n > 0) {
+            for (int j = pb.n + 1; j <= PREP_MAXB; ++j) pb.blk0[j] = pb.blk0[pb.n];
+            DISPATCH_T(ops[*n_done].dtype, hipLaunchKernelGGL(k_prep_weights_multi<T>, dim3(pb.blk0[pb.n]), dim3(kThreads), 0, st, pb));
+            FNET_LAUNCH_CHECK();
+            *n_done += pb.n;
+        }
+        if (rc != FNET_OK) return rc;
+    }
     return FNET_OK;
 }
 

@@ -143,6 +143,7 @@ int fnet_device_info(int32_t out[4]) {
 int fnet_plan_run(const FnetOp* ops, int32_t n_ops, void* stream, int32_t* failed_index) {
     if (!ops || n_ops < 0) return FNET_E_BADARG;
     hipStream_t caller = (hipStream_t)stream;
+    static const bool prep_batching = [] { const char* e = getenv("FNET_PREP_BATCH"); return !e || e[0] != '0'; }();   // A/B switch
     for (int32_t k = 0; k < n_ops; ++k) {
         hipStream_t st = caller;
         int rc = lane_stream(ops[k].i[FNET_LANE_SLOT], caller, &st);
@@ -154,6 +155,15 @@ int fnet_plan_run(const FnetOp* ops, int32_t n_ops, void* stream, int32_t* faile
                     const hipError_t e = ops[k].op == FNET_OP_EVENT_RECORD ? hipEventRecord(ev, st) : hipStreamWaitEvent(st, ev, 0);
                     if (e != hipSuccess) { g_fnet_last_hip_error = (int)e; rc = FNET_E_HIP; }
                 }
+            } else if (ops[k].op == FNET_OP_PREP_WEIGHTS && k + 1 < n_ops && ops[k + 1].op == FNET_OP_PREP_WEIGHTS && prep_batching) {
+                // a run of weight re-layouts (the start of every training step) goes out as one launch per 32 records
+                int32_t m = 1;
+                while (k + m < n_ops && ops[k + m].op == FNET_OP_PREP_WEIGHTS && ops[k + m].dtype == ops[k].dtype &&
+                       ops[k + m].i[FNET_LANE_SLOT] == ops[k].i[FNET_LANE_SLOT])
+                    ++m;
+                int done = 0;
+                rc = fnet_op_prep_weights_batch(ops + k, m, st, &done);
+                k += rc == FNET_OK ? m - 1 : done;            // on failure k is the offending record
             } else {
                 rc = dispatch_op(ops[k], st);
             }

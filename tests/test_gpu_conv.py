@@ -197,3 +197,52 @@ def test_stride2_big_tile_kernels():
                         "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert f"{len(S2_SHAPES)} passed" in r.stdout, r.stdout[-2000:]
+
+
+@pytest.mark.parametrize("name", ["medium-bf16", "large-depth4-bf16", "tiny-transpose-fp32", "small-medium-base20-bf16"])
+def test_prep_weights_batch_equals_record_by_record(name):
+    """fnet_plan_run hands a run of consecutive PREP_WEIGHTS records over as one launch per 32 records (k_prep_weights_multi); every
+    re-laid-out weight tensor (3x3, stride-2 2x2 form, transposed 2x2; zero-padded channel counts; > 32 records) must equal, bit for bit,
+    what the records write when executed one at a time."""
+    import fluidnet_oracle as orc
+    from fluidnet_amd.engine.rollout_plan import RolloutInferPlan
+    from fluidnet_amd.models.unet import UNet, UNetConfig
+    cfg, prec = {
+        "medium-bf16": (orc.medium_config(dropout=0.0), "bf16"),
+        "large-depth4-bf16": (orc.medium_config(dropout=0.0, base_channels=48, depth=4, downsample="avgpool"), "bf16"),
+        "tiny-transpose-fp32": (tiny_cfg(upsample="transpose"), "fp32"),
+        "small-medium-base20-bf16": (orc.medium_config(dropout=0.0, base_channels=20, downsample="avgpool"), "bf16"),
+    }[name]
+    m = UNet(UNetConfig(**cfg.__dict__), precision=prec)
+    m.load_state_dict(orc.make_params(cfg, seed=11))
+    m = m.cuda().eval()
+    plan = RolloutInferPlan(m.cfg, 1, 32, 32, params_flat=m.flat_params, dtype=prec)
+    bufs = [c[k] for c in plan.pb.convs.values() for k in ("Wf", "Wd") if c.get(k) is not None and getattr(c[k], "tensor", None) is not None]
+    assert len(plan._prep) >= 8
+
+    def snapshot():
+        torch.cuda.synchronize()
+        return [b.tensor.clone() for b in bufs]
+
+    for b in bufs:
+        b.tensor.fill_(3.0)
+    for k in range(len(plan._prep)):
+        rt.run_ops(plan._prep[k:k + 1])          # one record per call: the single-record kernels
+    one = snapshot()
+    for b in bufs:
+        b.tensor.fill_(5.0)
+    rt.run_ops(plan._prep)                       # the whole run: batched
+    many = snapshot()
+    for a, b_ in zip(one, many):
+        assert torch.equal(a.view(torch.uint8), b_.view(torch.uint8))
+    # a bad record inside a run: the records before it are executed, the error names its index
+    bad = plan._prep.copy()
+    bad[3]["i"][0] = 0                           # Cout = 0
+    for b in bufs:
+        b.tensor.fill_(7.0)
+    with pytest.raises(rt.FluidNetHipError) as ei:
+        rt.run_ops(bad)
+    assert "at op #3 (PREP_WEIGHTS)" in str(ei.value)
+    rt.run_ops(plan._prep)
+    for a, b_ in zip(one, snapshot()):
+        assert torch.equal(a.view(torch.uint8), b_.view(torch.uint8))

@@ -32,6 +32,7 @@ from fluidnet_amd.training.physics_loss import PhysicsAwareLoss  # noqa: E402
 from fluidnet_amd.training.trainer import step_seed  # noqa: E402
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0      # MI355X dense bf16 (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0               # MI355X HBM3E (MI355X_MICROARCH.md: ~8 TB/s)
 HBM_PEAK_GBS = 8000.0
 
 
@@ -202,10 +203,12 @@ def profile_ops(plan_arrays, recs_by_section, dump_path=None):
             a["ms"] += ms
             a["n"] += 1
             a["flops"] += r.flops
+            esz = 2 if r.dtype == rt.BF16 else 4
             if kind.startswith("CONV3X3"):
                 # algorithmic bytes of one launch: the input pixels once, the output pixels once, the 9 weight slices once
-                esz = 2 if r.dtype == rt.BF16 else 4
                 a["bytes"] += esz * (r.i[0] * (r.i[2] + r.i[5]) + 9 * r.i[2] * r.i[5])
+            else:
+                a["bytes"] += hbm_bytes(kind, r, esz)
     if dump_path:
         os.makedirs(os.path.dirname(dump_path) or ".", exist_ok=True)
         with open(dump_path, "w") as f:
@@ -213,6 +216,52 @@ def profile_ops(plan_arrays, recs_by_section, dump_path=None):
             for (name, k, kind, tag, ms, fl, iv) in rows:
                 f.write(f"{name},{k},{kind},{tag},{ms:.4f},{fl / 1e9:.3f},{(fl / (ms * 1e-3) / 1e12) if ms > 0 else 0:.1f},{' '.join(map(str, iv))}\n")
     return agg
+
+
+def hbm_bytes(kind, r, esz):
+    """Algorithmic HBM bytes of one launch of a bandwidth-bound op: every tensor it must read once + every tensor it must write once
+    (record layouts: include/fluidnet_ops.h); 0 for ops that are not accounted."""
+    def has(k):
+        return k < len(r.p) and r.p[k] is not None
+    if kind in ("IN_STATS", "APPLY", "INACT_BWD_REDUCE", "INACT_BWD_APPLY", "FOLD_SUM", "BIAS_GRAD"):
+        B, H, W, C = r.i[0], r.i[1], r.i[2], r.i[3]
+        inner, padded = B * H * W * C * esz, B * (H + 2) * (W + 2) * C * esz
+        if kind == "IN_STATS":
+            return inner                                          # raw once
+        if kind == "APPLY":
+            return padded * (2 + (1 if has(4) else 0))            # raw (+ residual) in, activation out (ring included)
+        if kind == "INACT_BWD_REDUCE":
+            return inner * (2 + (1 if has(1) else 0) + (1 if has(6) else 0))      # g1 (+ g2), raw in (+ G out)
+        if kind == "INACT_BWD_APPLY":
+            return 2 * inner + padded                             # G, raw in; d_raw out (ring zeroed)
+        if kind == "FOLD_SUM":
+            return inner * (1 + (1 if has(1) else 0)) + padded
+        return inner                                              # BIAS_GRAD
+    if kind in ("UPSAMPLE2X", "UPSAMPLE2X_BWD"):
+        B, h, w, C = r.i[0], r.i[1], r.i[2], r.i[3]
+        return B * C * esz * (h * w + 4 * h * w)                  # the coarse tensor on one side, the fine one on the other
+    if kind in ("LOSS_REDUCE", "LOSS_GRAD"):
+        B, H, W = r.i[0], r.i[1], r.i[2]
+        planes = 3 + 3 + 1 + 2 + (3 if kind == "LOSS_GRAD" else 0)    # pred, target, density_t, two masks (+ d pred out), fp32 planes
+        return B * H * W * 4 * planes
+    if kind == "ADAM":
+        n = r.i[0] + (r.i[1] << 31)
+        return n * 4 * 7                                          # p, g, m, v in; p, m, v out
+    return 0
+
+
+def hbm_roofline(agg):
+    """The bandwidth-bound families (norm / activation passes, loss stencils, resampling, optimiser): algorithmic bytes per step over the
+    HIP-event time of their launches, against the HBM data-sheet figure (MI355X_MICROARCH.md: ~8 TB/s; a read-mostly streaming kernel
+    reaches ~5.2 TB/s on these boxes)."""
+    hb = {k: v for k, v in agg.items() if v["bytes"] > 0 and v["ms"] > 0 and not k.startswith("CONV3X3")}
+    if not hb:
+        return None
+    tb, tms = sum(v["bytes"] for v in hb.values()), sum(v["ms"] for v in hb.values())
+    return {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "achieved": round(tb / (tms * 1e-3) / 1e9, 1),
+            "frac": round(tb / (tms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_gb_per_step": round(tb / 1e9, 2), "ms_per_step": round(tms, 3),
+            "kernels": {k: {"gb_per_s": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1), "ms_per_step": round(v["ms"], 3), "launches": v["n"]}
+                        for k, v in sorted(hb.items(), key=lambda kv: -kv[1]["ms"])}}
 
 
 def reference_gemm():
@@ -349,6 +398,9 @@ def measure_rollout(a, R, batch, frames, warm, world, rank, profile=True, dump=N
         out["roofline"] = {"bound": "mfma", "kernel": "k_conv3x3_dma", "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS,
                            "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
                            "launches_per_step": conv["n"], "avg_launch_ms": round(conv["ms"] / conv["n"], 4)}
+        hb = hbm_roofline(agg)
+        if hb:
+            out["hbm_roofline"] = hb
         out["breakdown_ms_per_step"] = {k: round(v["ms"], 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
     return out
 
@@ -429,6 +481,9 @@ def main():
                                "algorithmic_bytes_per_launch": round(conv["bytes"] / conv["n"])}
             if default_wl:
                 out["roofline"]["reference_gemm"] = reference_gemm()
+            hb = hbm_roofline(agg)
+            if hb:
+                out["hbm_roofline"] = hb
             out["breakdown_ms_per_step"] = {k: round(v["ms"], 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
             out["breakdown_ms_per_step"]["_sum"] = round(tot, 3)
             wg = agg.get("WGRAD_MFMA")
@@ -445,7 +500,8 @@ def main():
             if rank == 0:
                 out["rollout"] = {"metric": ro["metric"], "value": ro["value"], "unit": ro["unit"], "frames": ro["steps"], "scenes_per_gpu": 64,
                                   "resolution": 256, "ms_per_frame_step": ro["ms_per_step"], "state_finite": ro["config"]["state_finite"],
-                                  "conv_tflops": ro.get("roofline", {}).get("achieved"), "conv_frac": ro.get("roofline", {}).get("frac")}
+                                  "conv_tflops": ro.get("roofline", {}).get("achieved"), "conv_frac": ro.get("roofline", {}).get("frac"),
+                                  "hbm_gb_per_s": ro.get("hbm_roofline", {}).get("achieved"), "hbm_frac": ro.get("hbm_roofline", {}).get("frac")}
     else:
         R = a.res or 256
         frames = a.steps if a.steps is not None else 600

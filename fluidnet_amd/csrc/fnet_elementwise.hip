@@ -336,31 +336,13 @@ __global__ __launch_bounds__(256) void k_norm_combine_bwd(const float2* S, const
     }
 }
 
-// ------------------------------------------------------------------ APPLY
-// dst[n,y,x,c] = act(gamma*(raw[src]-mean)*rstd+beta) * drop(n,c) + res[src], over the padded domain
+// The pixel walk of APPLY for one thread's 8 channels: padded positions p, p + ps, ... < p1 of one image (shared by k_apply and k_stats_apply, so
+// that both produce the same bits from the same constants)
 template <typename T, int ACT>
-__global__ __launch_bounds__(256) void k_apply(const T* __restrict__ raw, const float2* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta, const T* __restrict__ res, T* __restrict__ dst,
-                        int H, int W, int C, int ldc_raw, int coff_raw, int ldc_res, int coff_res, int ldc_dst,
-                        int coff_dst, int act, int pm, uint32_t site, uint32_t seed, float drop_p, int p_per_block) {
-    const CgMap m(C);
-    if (!m.active) return;
-    const int n = blockIdx.y, Hp = H + 2, Wp = W + 2, c0 = m.cg * 8;
-    int p, ps, p1;
-    m.range(Hp * Wp, p_per_block, p, ps, p1);
-    float ca[8], cb[8], dsc[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        if (stats) {
-            const float2 ms = stats[(size_t)n * C + c0 + k];
-            ca[k] = ms.y * gamma[c0 + k];
-            cb[k] = fmaf(-ms.x, ca[k], beta[c0 + k]);
-        } else { ca[k] = 1.f; cb[k] = 0.f; }
-        dsc[k] = drop_scale(seed, site, n, c0 + k, drop_p);
-    }
-    const size_t img = (size_t)n * Hp * Wp;
-    const T* rbase = raw + img * ldc_raw + coff_raw + c0;
-    const T* sbase = res ? res + img * ldc_res + coff_res + c0 : nullptr;
-    T* dbase = dst + img * ldc_dst + coff_dst + c0;
+__device__ __forceinline__ void apply_walk(const T* __restrict__ rbase, const T* __restrict__ sbase, T* __restrict__ dbase, const float (&ca)[8],
+                                           const float (&cb)[8], const float (&dsc)[8], int H, int W, int ldc_raw, int ldc_res, int ldc_dst, int pm,
+                                           int p, int ps, int p1) {
+    const int Wp = W + 2;
     PixWalk w(p, ps, Wp);
     const int ylo = pad_lo(H, pm), yhi = pad_hi(H, pm), xlo = pad_lo(W, pm), xhi = pad_hi(W, pm);
     auto trip = [&](auto uc, auto rc) {
@@ -405,6 +387,127 @@ __global__ __launch_bounds__(256) void k_apply(const T* __restrict__ raw, const 
         for (; p + (U - 1) * ps < p1; p += U * ps) trip(IntC<U>{}, IntC<0>{});
         for (; p < p1; p += ps) trip(IntC<1>{}, IntC<0>{});
     }
+}
+
+// ------------------------------------------------------------------ APPLY
+// dst[n,y,x,c] = act(gamma*(raw[src]-mean)*rstd+beta) * drop(n,c) + res[src], over the padded domain
+template <typename T, int ACT>
+__global__ __launch_bounds__(256) void k_apply(const T* __restrict__ raw, const float2* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta, const T* __restrict__ res, T* __restrict__ dst,
+                        int H, int W, int C, int ldc_raw, int coff_raw, int ldc_res, int coff_res, int ldc_dst,
+                        int coff_dst, int act, int pm, uint32_t site, uint32_t seed, float drop_p, int p_per_block) {
+    const CgMap m(C);
+    if (!m.active) return;
+    const int n = blockIdx.y, Hp = H + 2, Wp = W + 2, c0 = m.cg * 8;
+    int p, ps, p1;
+    m.range(Hp * Wp, p_per_block, p, ps, p1);
+    float ca[8], cb[8], dsc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        if (stats) {
+            const float2 ms = stats[(size_t)n * C + c0 + k];
+            ca[k] = ms.y * gamma[c0 + k];
+            cb[k] = fmaf(-ms.x, ca[k], beta[c0 + k]);
+        } else { ca[k] = 1.f; cb[k] = 0.f; }
+        dsc[k] = drop_scale(seed, site, n, c0 + k, drop_p);
+    }
+    const size_t img = (size_t)n * Hp * Wp;
+    const T* rbase = raw + img * ldc_raw + coff_raw + c0;
+    const T* sbase = res ? res + img * ldc_res + coff_res + c0 : nullptr;
+    T* dbase = dst + img * ldc_dst + coff_dst + c0;
+    apply_walk<T, ACT>(rbase, sbase, dbase, ca, cb, dsc, H, W, ldc_raw, ldc_res, ldc_dst, pm, p, ps, p1);
+}
+
+// ------------------------------------------------------------------ IN_STATS + APPLY in one launch (small images)
+// InstanceNorm statistics, their finalisation and the normalise / activate pass of one unit as ONE kernel, for images whose 32-channel
+// slab one block can walk twice: block = (image n, 32-channel slice), 1024 threads = 4 channel groups x 256 pixel lanes.  Pass 1 sums x
+// and x^2 over the interior (fp32, fixed order: per thread, across the 16 lanes of a wave that share a channel group, across the 16 waves);
+// (mean, rstd) go to `stats` for the backward pass and stay in LDS for pass 2, which is APPLY's own pixel walk (apply_walk) reading the
+// slab a second time from L2.  Replaces three launches (k_in_stats_part, k_in_finalize, k_apply) whose fixed cost (~10 us each: launch
+// ramp, constant loads, a first load round trip, drain) exceeds their traffic time on the <= 64^2 layers: 72 of a step's 104 units.
+// Blocks of one image sit on one XCD back to back (item = (b % 8) * ceil(items / 8) + b / 8): its slices share 128-B lines.
+constexpr int SA_THREADS = 1024, SA_CS = 32, SA_GROUPS = SA_CS / 8, SA_PPI = SA_THREADS / SA_GROUPS;
+template <typename T, int ACT>
+__global__ __launch_bounds__(SA_THREADS) void k_stats_apply(const T* __restrict__ raw, float2* __restrict__ stats, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, const T* __restrict__ res, T* __restrict__ dst, int B, int H,
+                                                            int W, int C, int ldc_raw, int coff_raw, int ldc_res, int coff_res, int ldc_dst, int coff_dst,
+                                                            int pm, uint32_t site, uint32_t seed, float drop_p, float eps) {
+    __shared__ float red[SA_THREADS / 64][SA_GROUPS][16];
+    __shared__ float2 cst[SA_CS];
+    const int nslices = C / SA_CS, items = nslices * B, per = (items + 7) >> 3;
+    const int item = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= per || item >= items) return;            // (whole block: no barrier has been reached)
+    const int n = item / nslices, slice = item - n * nslices;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cg = tid & (SA_GROUPS - 1), px = tid / SA_GROUPS;
+    const int c0 = slice * SA_CS + cg * 8;
+    const int Hp = H + 2, Wp = W + 2, HW = H * W;
+    const size_t img = (size_t)n * Hp * Wp;
+    const T* rbase = raw + img * ldc_raw + coff_raw + c0;
+    float s[8], t[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { s[k] = 0.f; t[k] = 0.f; }
+    {
+        int q = px;
+        PixWalk w(q, SA_PPI, W);
+        auto trip = [&](auto uc) {
+            constexpr int UU = decltype(uc)::value;
+            Raw8<T> r[UU];
+#pragma unroll
+            for (int u = 0; u < UU; ++u) {
+                r[u].load(rbase + pix_off(pix_of(w.y + 1, w.x + 1, Wp), ldc_raw));
+                w.step();
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < UU; ++u) {
+                float v[8];
+                r[u].unpack(v);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { s[k] += v[k]; t[k] = fmaf(v[k], v[k], t[k]); }
+            }
+        };
+        constexpr int U = 4;
+        for (; q + (U - 1) * SA_PPI < HW; q += U * SA_PPI) trip(IntC<U>{});
+        for (; q < HW; q += SA_PPI) trip(IntC<1>{});
+    }
+    // lanes l, l + 4, l + 8, ... of a wave share a channel group
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+#pragma unroll
+        for (int d = SA_GROUPS; d < 64; d <<= 1) {
+            s[k] += __shfl_xor(s[k], d);
+            t[k] += __shfl_xor(t[k], d);
+        }
+    }
+    if (lane < SA_GROUPS) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { red[wave][lane][k] = s[k]; red[wave][lane][8 + k] = t[k]; }
+    }
+    __syncthreads();
+    if (tid < SA_CS) {
+        const int g = tid >> 3, k = tid & 7;
+        float sx = 0.f, sq = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < SA_THREADS / 64; ++wv) { sx += red[wv][g][k]; sq += red[wv][g][8 + k]; }
+        const float inv_hw = 1.f / (float)HW;
+        const float mean = sx * inv_hw;
+        const float var = fmaxf(sq * inv_hw - mean * mean, 0.f);
+        const float2 ms = make_float2(mean, rsqrtf(var + eps));
+        cst[tid] = ms;
+        stats[(size_t)n * C + slice * SA_CS + tid] = ms;
+    }
+    __syncthreads();
+    float ca[8], cb[8], dsc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float2 ms = cst[cg * 8 + k];
+        ca[k] = ms.y * gamma[c0 + k];
+        cb[k] = fmaf(-ms.x, ca[k], beta[c0 + k]);
+        dsc[k] = drop_scale(seed, site, n, c0 + k, drop_p);
+    }
+    const T* sbase = res ? res + img * ldc_res + coff_res + c0 : nullptr;
+    T* dbase = dst + img * ldc_dst + coff_dst + c0;
+    apply_walk<T, ACT>(rbase, sbase, dbase, ca, cb, dsc, H, W, ldc_raw, ldc_res, ldc_dst, pm, px, SA_PPI, Hp * Wp);
 }
 
 // ------------------------------------------------------------------ gradient read with ring fold
@@ -1180,6 +1283,36 @@ int fnet_op_apply(const FnetOp& op, hipStream_t st) {
                                             (const float*)op.p[3], (const T*)op.p[4], (T*)op.p[5], H, W, C, op.i[4],
                                             op.i[5], op.i[6], op.i[7], op.i[8], op.i[9], op.i[10], op.i[11],
                                             (uint32_t)op.i[12], (uint32_t)op.i[13], op.f[0], per)));
+    FNET_LAUNCH_CHECK();
+    return FNET_OK;
+}
+
+// IN_STATS immediately followed by the APPLY of the same unit (InstanceNorm: nothing pools the statistics in between), on a small image:
+// one k_stats_apply launch instead of three.  fnet_plan_run asks fnet_can_fuse_stats_apply first; anything it does not cover -- and any
+// record that would fail its own checks -- takes the two ordinary launchers (which then report the error).  FNET_FUSE_SMALL=0 disables it.
+bool fnet_can_fuse_stats_apply(const FnetOp& so, const FnetOp& ao) {
+    static const bool on = [] { const char* e = getenv("FNET_FUSE_SMALL"); return !e || e[0] != '0'; }();
+    if (!on || so.dtype != FNET_BF16 || ao.dtype != FNET_BF16 || so.i[FNET_LANE_SLOT] != ao.i[FNET_LANE_SLOT]) return false;
+    for (int k = 0; k < 6; ++k)
+        if (so.i[k] != ao.i[k]) return false;                       // B, H, W, C, ldc, coff of raw
+    const int B = ao.i[0], H = ao.i[1], W = ao.i[2], C = ao.i[3];
+    if (so.p[0] != ao.p[0] || !so.p[1] || so.p[1] != ao.p[1] || !ao.p[2] || !ao.p[3] || !ao.p[5]) return false;
+    if (B <= 0 || H < 2 || W < 2 || C % SA_CS != 0 || (long long)(H + 2) * (W + 2) > 66 * 66) return false;
+    if (!vec_ok((void*)ao.p[0], ao.i[4], ao.i[5], C, ao.dtype) || !vec_ok_opt((void*)ao.p[4], ao.i[6], ao.i[7], C, ao.dtype) ||
+        !vec_ok((void*)ao.p[5], ao.i[8], ao.i[9], C, ao.dtype))
+        return false;
+    if (ao.i[10] < 0 || ao.i[10] > 4 || ao.i[11] < 0 || ao.i[11] > 3 || !(ao.f[0] >= 0.f && ao.f[0] < 1.f) || !cg_ok(C, B)) return false;
+    return off_ok(H, W, ao.i[4], ao.p[4] ? ao.i[6] : 8, ao.i[8]) && (long long)B * (C / SA_CS) < (1ll << 30);
+}
+int fnet_op_stats_apply(const FnetOp& so, const FnetOp& op, hipStream_t st) {
+    FNET_CHECK_ARG(fnet_can_fuse_stats_apply(so, op));
+    const int B = op.i[0], H = op.i[1], W = op.i[2], C = op.i[3];
+    const int items = B * (C / SA_CS);
+    using T = bf16_t;
+    DISPATCH_ACT(op.i[10], hipLaunchKernelGGL((k_stats_apply<T, ACT>), dim3((items + 7) / 8 * 8), dim3(SA_THREADS), 0, st, (const T*)op.p[0],
+                                              (float2*)op.p[1], (const float*)op.p[2], (const float*)op.p[3], (const T*)op.p[4], (T*)op.p[5], B, H, W,
+                                              C, op.i[4], op.i[5], op.i[6], op.i[7], op.i[8], op.i[9], op.i[11], (uint32_t)op.i[12],
+                                              (uint32_t)op.i[13], op.f[0], so.f[0]));
     FNET_LAUNCH_CHECK();
     return FNET_OK;
 }

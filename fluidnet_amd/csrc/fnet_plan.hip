@@ -155,6 +155,10 @@ int fnet_plan_run(const FnetOp* ops, int32_t n_ops, void* stream, int32_t* faile
                     const hipError_t e = ops[k].op == FNET_OP_EVENT_RECORD ? hipEventRecord(ev, st) : hipStreamWaitEvent(st, ev, 0);
                     if (e != hipSuccess) { g_fnet_last_hip_error = (int)e; rc = FNET_E_HIP; }
                 }
+            } else if (ops[k].op == FNET_OP_IN_STATS && k + 1 < n_ops && ops[k + 1].op == FNET_OP_APPLY &&
+                       fnet_can_fuse_stats_apply(ops[k], ops[k + 1])) {
+                rc = fnet_op_stats_apply(ops[k], ops[k + 1], st);      // one launch for the pair (small images)
+                if (rc == FNET_OK) ++k;
             } else if (ops[k].op == FNET_OP_PREP_WEIGHTS && k + 1 < n_ops && ops[k + 1].op == FNET_OP_PREP_WEIGHTS && prep_batching) {
                 // a run of weight re-layouts (the start of every training step) goes out as one launch per 32 records
                 int32_t m = 1;

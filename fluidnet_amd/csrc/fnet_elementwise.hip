@@ -425,12 +425,17 @@ __global__ __launch_bounds__(256) void k_apply(const T* __restrict__ raw, const 
 // slab a second time from L2.  Replaces three launches (k_in_stats_part, k_in_finalize, k_apply) whose fixed cost (~10 us each: launch
 // ramp, constant loads, a first load round trip, drain) exceeds their traffic time on the <= 64^2 layers: 72 of a step's 104 units.
 // Blocks of one image sit on one XCD back to back (item = (b % 8) * ceil(items / 8) + b / 8): its slices share 128-B lines.
-constexpr int SA_THREADS = 1024, SA_CS = 32, SA_GROUPS = SA_CS / 8, SA_PPI = SA_THREADS / SA_GROUPS;
-template <typename T, int ACT>
+// SA_CS = channels per slice: 64, 32 or 16 -- the widest that still leaves a block per CU (UNet_medium at B = 64: exactly 256 blocks on every layer).
+constexpr int SA_THREADS = 1024;
+#ifndef FNET_SA_U1
+#define FNET_SA_U1 4
+#endif
+template <typename T, int ACT, int SA_CS>
 __global__ __launch_bounds__(SA_THREADS) void k_stats_apply(const T* __restrict__ raw, float2* __restrict__ stats, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, const T* __restrict__ res, T* __restrict__ dst, int B, int H,
                                                             int W, int C, int ldc_raw, int coff_raw, int ldc_res, int coff_res, int ldc_dst, int coff_dst,
                                                             int pm, uint32_t site, uint32_t seed, float drop_p, float eps) {
+    constexpr int SA_GROUPS = SA_CS / 8, SA_PPI = SA_THREADS / SA_GROUPS;
     __shared__ float red[SA_THREADS / 64][SA_GROUPS][16];
     __shared__ float2 cst[SA_CS];
     const int nslices = C / SA_CS, items = nslices * B, per = (items + 7) >> 3;
@@ -466,7 +471,7 @@ __global__ __launch_bounds__(SA_THREADS) void k_stats_apply(const T* __restrict_
                 for (int k = 0; k < 8; ++k) { s[k] += v[k]; t[k] = fmaf(v[k], v[k], t[k]); }
             }
         };
-        constexpr int U = 4;
+        constexpr int U = FNET_SA_U1;
         for (; q + (U - 1) * SA_PPI < HW; q += U * SA_PPI) trip(IntC<U>{});
         for (; q < HW; q += SA_PPI) trip(IntC<1>{});
     }
@@ -1290,6 +1295,10 @@ int fnet_op_apply(const FnetOp& op, hipStream_t st) {
 // IN_STATS immediately followed by the APPLY of the same unit (InstanceNorm: nothing pools the statistics in between), on a small image:
 // one k_stats_apply launch instead of three.  fnet_plan_run asks fnet_can_fuse_stats_apply first; anything it does not cover -- and any
 // record that would fail its own checks -- takes the two ordinary launchers (which then report the error).  FNET_FUSE_SMALL=0 disables it.
+static long long sa_max_pixels() {       // padded pixels per image up to which the pair is fused (FNET_SA_MAXHW = the image side, tuning knob)
+    static const long long v = [] { const char* e = getenv("FNET_SA_MAXHW"); const long long s = e ? atoll(e) : 64; return (s + 2) * (s + 2); }();
+    return v;
+}
 bool fnet_can_fuse_stats_apply(const FnetOp& so, const FnetOp& ao) {
     static const bool on = [] { const char* e = getenv("FNET_FUSE_SMALL"); return !e || e[0] != '0'; }();
     if (!on || so.dtype != FNET_BF16 || ao.dtype != FNET_BF16 || so.i[FNET_LANE_SLOT] != ao.i[FNET_LANE_SLOT]) return false;
@@ -1297,22 +1306,30 @@ bool fnet_can_fuse_stats_apply(const FnetOp& so, const FnetOp& ao) {
         if (so.i[k] != ao.i[k]) return false;                       // B, H, W, C, ldc, coff of raw
     const int B = ao.i[0], H = ao.i[1], W = ao.i[2], C = ao.i[3];
     if (so.p[0] != ao.p[0] || !so.p[1] || so.p[1] != ao.p[1] || !ao.p[2] || !ao.p[3] || !ao.p[5]) return false;
-    if (B <= 0 || H < 2 || W < 2 || C % SA_CS != 0 || (long long)(H + 2) * (W + 2) > 66 * 66) return false;
+    if (B <= 0 || H < 2 || W < 2 || C % 16 != 0 || (long long)(H + 2) * (W + 2) > sa_max_pixels()) return false;
     if (!vec_ok((void*)ao.p[0], ao.i[4], ao.i[5], C, ao.dtype) || !vec_ok_opt((void*)ao.p[4], ao.i[6], ao.i[7], C, ao.dtype) ||
         !vec_ok((void*)ao.p[5], ao.i[8], ao.i[9], C, ao.dtype))
         return false;
     if (ao.i[10] < 0 || ao.i[10] > 4 || ao.i[11] < 0 || ao.i[11] > 3 || !(ao.f[0] >= 0.f && ao.f[0] < 1.f) || !cg_ok(C, B)) return false;
-    return off_ok(H, W, ao.i[4], ao.p[4] ? ao.i[6] : 8, ao.i[8]) && (long long)B * (C / SA_CS) < (1ll << 30);
+    return off_ok(H, W, ao.i[4], ao.p[4] ? ao.i[6] : 8, ao.i[8]) && (long long)B * (C / 16) < (1ll << 30);
 }
 int fnet_op_stats_apply(const FnetOp& so, const FnetOp& op, hipStream_t st) {
     FNET_CHECK_ARG(fnet_can_fuse_stats_apply(so, op));
     const int B = op.i[0], H = op.i[1], W = op.i[2], C = op.i[3];
-    const int items = B * (C / SA_CS);
+    const char* ecs = getenv("FNET_SA_CS");                  // 16 | 32 forces the slice width (read per launch: the tests run both)
+    const int forced_cs = ecs ? atoi(ecs) : 0;
+    // the widest slice (whole 128-B / 64-B pixel segments) that still gives every CU a block
+    int cs = (C % 64 == 0 && (long long)B * (C / 64) >= 256) ? 64 : (C % 32 == 0 && (long long)B * (C / 32) >= 256) ? 32 : 16;
+    if (forced_cs == 16 || (forced_cs == 32 && C % 32 == 0) || (forced_cs == 64 && C % 64 == 0)) cs = forced_cs;
+    const int items = B * (C / cs);
     using T = bf16_t;
-    DISPATCH_ACT(op.i[10], hipLaunchKernelGGL((k_stats_apply<T, ACT>), dim3((items + 7) / 8 * 8), dim3(SA_THREADS), 0, st, (const T*)op.p[0],
-                                              (float2*)op.p[1], (const float*)op.p[2], (const float*)op.p[3], (const T*)op.p[4], (T*)op.p[5], B, H, W,
-                                              C, op.i[4], op.i[5], op.i[6], op.i[7], op.i[8], op.i[9], op.i[11], (uint32_t)op.i[12],
-                                              (uint32_t)op.i[13], op.f[0], so.f[0]));
+#define FNET_SA_LAUNCH(CS_)                                                                                                                    \
+    DISPATCH_ACT(op.i[10], hipLaunchKernelGGL((k_stats_apply<T, ACT, CS_>), dim3((items + 7) / 8 * 8), dim3(SA_THREADS), 0, st,                  \
+                                              (const T*)op.p[0], (float2*)op.p[1], (const float*)op.p[2], (const float*)op.p[3],               \
+                                              (const T*)op.p[4], (T*)op.p[5], B, H, W, C, op.i[4], op.i[5], op.i[6], op.i[7], op.i[8], op.i[9], \
+                                              op.i[11], (uint32_t)op.i[12], (uint32_t)op.i[13], op.f[0], so.f[0]))
+    if (cs == 64) { FNET_SA_LAUNCH(64); } else if (cs == 32) { FNET_SA_LAUNCH(32); } else { FNET_SA_LAUNCH(16); }
+#undef FNET_SA_LAUNCH
     FNET_LAUNCH_CHECK();
     return FNET_OK;
 }

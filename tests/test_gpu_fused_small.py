@@ -62,8 +62,10 @@ def _run(arr, st, dst, together):
     return st.tensor.clone(), dst.tensor.float().clone()
 
 
+@pytest.mark.parametrize("cs", ["16", "32", "64"])
 @pytest.mark.parametrize("case", CASES, ids=[f"B{c[0]}_{c[1]}x{c[2]}_C{c[3]}_{c[7]}_pm{c[8]}" for c in CASES])
-def test_fused_stats_apply_equals_separate_launches(case):
+def test_fused_stats_apply_equals_separate_launches(case, cs, monkeypatch):
+    monkeypatch.setenv("FNET_SA_CS", cs)       # every slice width of the kernel (64 falls back where C % 64 != 0) (the launcher picks by block count otherwise)
     pb, ops, st, dst = _mk(*case)
     arr = lower(pb, ops)
     s1, d1 = _run(arr, st, dst, together=False)

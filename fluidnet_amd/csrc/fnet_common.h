@@ -308,6 +308,8 @@ FNET_DECL_OP(fnet_op_zero);
 FNET_DECL_OP(fnet_op_prep_weights);
 bool fnet_can_fuse_stats_apply(const FnetOp& stats_op, const FnetOp& apply_op);                          // IN_STATS + APPLY of one unit, small image
 int fnet_op_stats_apply(const FnetOp& stats_op, const FnetOp& apply_op, hipStream_t st);
+bool fnet_can_fuse_inact_bwd(const FnetOp& reduce_op, const FnetOp& apply_op);                             // INACT_BWD_REDUCE + INACT_BWD_APPLY, single source, small image
+int fnet_op_inact_bwd_fused(const FnetOp& reduce_op, const FnetOp& apply_op, hipStream_t st);
 int fnet_op_prep_weights_batch(const FnetOp* ops, int n, hipStream_t st, int* n_done);   // consecutive PREP_WEIGHTS records, one launch per 32
 FNET_DECL_OP(fnet_op_grad_norm);
 FNET_DECL_OP(fnet_op_adam);

@@ -556,6 +556,87 @@ __device__ __forceinline__ void fold_extras8(const T* gimg, int y, int x, int H,
         }
 }
 
+// Pass 1 of the norm / activation adjoint for one thread's 8 channels: interior pixels q, q + qs, ... < q1 of one image; adds dz to s and
+// dz * xhat to t, writes G where Gbase is given (shared by k_inact_bwd_reduce and k_inact_bwd_fused)
+template <typename T, int ACT>
+__device__ __forceinline__ void inact_reduce_walk(const T* __restrict__ g1img, const T* __restrict__ g2img, const T* __restrict__ rbase, T* __restrict__ Gbase,
+                                                  const float (&xa)[8], const float (&xb)[8], const float (&gam)[8], const float (&bet)[8],
+                                                  const float (&dsc)[8], float (&s)[8], float (&t)[8], int H, int W, int ldc_g1, int ldc_g2, int ldc_raw,
+                                                  int ldc_G, int fold1, int fold2, int pm, int q, int qs, int q1) {
+    const int Wp = W + 2;
+    const bool f1 = fold1 && pm != FNET_PAD_ZEROS, f2 = fold2 && pm != FNET_PAD_ZEROS;
+    const int fylo = pad_lo(H, pm), fyhi = pad_hi(H, pm), fxlo = pad_lo(W, pm), fxhi = pad_hi(W, pm);
+    PixWalk w(q, qs, W);
+    auto trip = [&](auto uc, auto gc) {
+        constexpr int UU = decltype(uc)::value;
+        constexpr bool G2 = decltype(gc)::value != 0;
+        Raw8<T> ra1[UU], ra2[UU], rr[UU];
+        uint32_t pix[UU];
+        int yy[UU], xx[UU];
+#pragma unroll
+        for (int u = 0; u < UU; ++u) {
+            yy[u] = w.y; xx[u] = w.x;
+            pix[u] = pix_of(w.y + 1, w.x + 1, Wp);
+            ra1[u].load(g1img + pix_off(pix[u], ldc_g1));
+            if (G2) ra2[u].load(g2img + pix_off(pix[u], ldc_g2));
+            rr[u].load(rbase + pix_off(pix[u], ldc_raw));
+            w.step();
+        }
+        __builtin_amdgcn_sched_barrier(0);     // every load of the trip is out before the first unpack (see Raw8)
+        Vec8<T> a1[UU], a2[UU], r[UU];
+#pragma unroll
+        for (int u = 0; u < UU; ++u) {
+            ra1[u].unpack(a1[u].v);
+            if (G2) ra2[u].unpack(a2[u].v);
+            rr[u].unpack(r[u].v);
+            float acc[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[k] = G2 ? a1[u].v[k] + a2[u].v[k] : a1[u].v[k];
+            if ((f1 || f2) && (yy[u] == fylo || yy[u] == fyhi || xx[u] == fxlo || xx[u] == fxhi)) {
+                // a pixel the ring copies (row/column 0 and n-1 for replicate and circular, 1 and n-2 for reflect): add the
+                // ring positions that are copies of it (same order as fold_read8: g1's, then g2's)
+                if (G2) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) acc[k] = a1[u].v[k];
+                }
+                if (f1) fold_extras8<T>(g1img, yy[u], xx[u], H, W, ldc_g1, pm, acc);
+                if (G2) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) acc[k] += a2[u].v[k];
+                    if (f2) fold_extras8<T>(g2img, yy[u], xx[u], H, W, ldc_g2, pm, acc);
+                } else if (sizeof(T) == 2) {
+                    // single source: only a folded pixel is a sum that needs rounding to the stored type (see below)
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) acc[k] = bf2f(f2bf(acc[k]));
+                }
+            }
+            Vec8<T> go;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) go.v[k] = acc[k];
+            if (Gbase) go.store_nt(Gbase + pix_off(pix[u], ldc_G));
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                // use the value as stored (bf16-rounded in bf16 mode) so that pass 2 sees the same G
+                const float xh = fmaf(r[u].v[k], xa[k], xb[k]);
+                const float uu = fmaf(xh, gam[k], bet[k]);
+                float gq = go.v[k];
+                if (sizeof(T) == 2 && G2) gq = bf2f(f2bf(gq));   // (one source: a stored value, or rounded where it was folded)
+                const float dz = gq * dsc[k] * act_bwd_t<ACT>(uu);
+                s[k] += dz;
+                t[k] = fmaf(dz, xh, t[k]);
+            }
+        }
+    };
+    constexpr int U = FNET_EW_UR;   // pixels per trip: the gradient and activation loads of all of them are issued first
+    if (g2img) {
+        for (; q + (U - 1) * qs < q1; q += U * qs) trip(IntC<U>{}, IntC<1>{});
+        for (; q < q1; q += qs) trip(IntC<1>{}, IntC<1>{});
+    } else {
+        for (; q + (U - 1) * qs < q1; q += U * qs) trip(IntC<U>{}, IntC<0>{});
+        for (; q < q1; q += qs) trip(IntC<1>{}, IntC<0>{});
+    }
+}
+
 // ------------------------------------------------------------------ INACT_BWD_REDUCE (pass 1)
 // G = fold(g1) + fold(g2); dz = G*drop*act'(u); S1 = sum dz, S2 = sum dz*xhat per (n,c).  Writes G (interior) and adds the
 // block's partial sums into S (zeroed by the plan before this op).
@@ -586,77 +667,7 @@ __global__ __launch_bounds__(256) void k_inact_bwd_reduce(const T* __restrict__ 
         T* Gbase = G ? G + img * ldc_G + coff_G + c0 : nullptr;    // G == 0: single-source unit, pass 2 re-reads (and re-folds) g1
         const T* g1img = g1 + img * ldc_g1 + coff_g1 + c0;
         const T* g2img = g2 ? g2 + img * ldc_g2 + coff_g2 + c0 : nullptr;
-        const bool f1 = fold1 && pm != FNET_PAD_ZEROS, f2 = fold2 && pm != FNET_PAD_ZEROS;
-        const int fylo = pad_lo(H, pm), fyhi = pad_hi(H, pm), fxlo = pad_lo(W, pm), fxhi = pad_hi(W, pm);
-        PixWalk w(q, qs, W);
-        auto trip = [&](auto uc, auto gc) {
-            constexpr int UU = decltype(uc)::value;
-            constexpr bool G2 = decltype(gc)::value != 0;
-            Raw8<T> ra1[UU], ra2[UU], rr[UU];
-            uint32_t pix[UU];
-            int yy[UU], xx[UU];
-#pragma unroll
-            for (int u = 0; u < UU; ++u) {
-                yy[u] = w.y; xx[u] = w.x;
-                pix[u] = pix_of(w.y + 1, w.x + 1, Wp);
-                ra1[u].load(g1img + pix_off(pix[u], ldc_g1));
-                if (G2) ra2[u].load(g2img + pix_off(pix[u], ldc_g2));
-                rr[u].load(rbase + pix_off(pix[u], ldc_raw));
-                w.step();
-            }
-            __builtin_amdgcn_sched_barrier(0);     // every load of the trip is out before the first unpack (see Raw8)
-            Vec8<T> a1[UU], a2[UU], r[UU];
-#pragma unroll
-            for (int u = 0; u < UU; ++u) {
-                ra1[u].unpack(a1[u].v);
-                if (G2) ra2[u].unpack(a2[u].v);
-                rr[u].unpack(r[u].v);
-                float acc[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) acc[k] = G2 ? a1[u].v[k] + a2[u].v[k] : a1[u].v[k];
-                if ((f1 || f2) && (yy[u] == fylo || yy[u] == fyhi || xx[u] == fxlo || xx[u] == fxhi)) {
-                    // a pixel the ring copies (row/column 0 and n-1 for replicate and circular, 1 and n-2 for reflect): add the
-                    // ring positions that are copies of it (same order as fold_read8: g1's, then g2's)
-                    if (G2) {
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) acc[k] = a1[u].v[k];
-                    }
-                    if (f1) fold_extras8<T>(g1img, yy[u], xx[u], H, W, ldc_g1, pm, acc);
-                    if (G2) {
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) acc[k] += a2[u].v[k];
-                        if (f2) fold_extras8<T>(g2img, yy[u], xx[u], H, W, ldc_g2, pm, acc);
-                    } else if (sizeof(T) == 2) {
-                        // single source: only a folded pixel is a sum that needs rounding to the stored type (see below)
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) acc[k] = bf2f(f2bf(acc[k]));
-                    }
-                }
-                Vec8<T> go;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) go.v[k] = acc[k];
-                if (Gbase) go.store_nt(Gbase + pix_off(pix[u], ldc_G));
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    // use the value as stored (bf16-rounded in bf16 mode) so that pass 2 sees the same G
-                    const float xh = fmaf(r[u].v[k], xa[k], xb[k]);
-                    const float uu = fmaf(xh, gam[k], bet[k]);
-                    float gq = go.v[k];
-                    if (sizeof(T) == 2 && G2) gq = bf2f(f2bf(gq));   // (one source: a stored value, or rounded where it was folded)
-                    const float dz = gq * dsc[k] * act_bwd_t<ACT>(uu);
-                    s[k] += dz;
-                    t[k] = fmaf(dz, xh, t[k]);
-                }
-            }
-        };
-        constexpr int U = FNET_EW_UR;   // pixels per trip: the gradient and activation loads of all of them are issued first
-        if (g2img) {
-            for (; q + (U - 1) * qs < q1; q += U * qs) trip(IntC<U>{}, IntC<1>{});
-            for (; q < q1; q += qs) trip(IntC<1>{}, IntC<1>{});
-        } else {
-            for (; q + (U - 1) * qs < q1; q += U * qs) trip(IntC<U>{}, IntC<0>{});
-            for (; q < q1; q += qs) trip(IntC<1>{}, IntC<0>{});
-        }
+        inact_reduce_walk<T, ACT>(g1img, g2img, rbase, Gbase, xa, xb, gam, bet, dsc, s, t, H, W, ldc_g1, ldc_g2, ldc_raw, ldc_G, fold1, fold2, pm, q, qs, q1);
     }
 #pragma unroll
     for (int k = 0; k < 8; ++k) { red[threadIdx.x * 16 + k] = s[k]; red[threadIdx.x * 16 + 8 + k] = t[k]; }
@@ -672,38 +683,13 @@ __global__ __launch_bounds__(256) void k_inact_bwd_reduce(const T* __restrict__ 
     }
 }
 
-// ------------------------------------------------------------------ INACT_BWD_APPLY (pass 2)
-// d_raw = gamma*rstd*(dz - S1/HW - xhat*S2/HW) on the interior, 0 on the ring (so that d_raw can feed
-// the flattened dgrad / wgrad convolutions directly).
-// WS ("weighted sums", BatchNorm2d / GroupNorm): S holds what NORM_COMBINE_BWD made of the per-(n,c) sums -- their gamma-weighted
-// mean over the normalisation group -- and d_raw = gamma*rstd*dz - rstd*(S1'/HW + xhat*S2'/HW).
+// Pass 2 for one thread's 8 channels: padded positions p, p + ps, ... < p1 of one image (shared by k_inact_bwd_apply and k_inact_bwd_fused)
 template <typename T, int ACT, bool WS>
-__global__ __launch_bounds__(256) void k_inact_bwd_apply(const T* __restrict__ G, const T* __restrict__ raw, const float2* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                  const float2* __restrict__ S, T* __restrict__ draw, int H, int W, int C, int ldc_G, int coff_G, int ldc_raw,
-                                  int coff_raw, int ldc_d, int coff_d, int act, uint32_t site, uint32_t seed, float drop_p,
-                                  int p_per_block, int fold, int pm) {
-    const CgMap m(C);
-    if (!m.active) return;
-    const int n = blockIdx.y, Hp = H + 2, Wp = W + 2, c0 = m.cg * 8;
-    int p, ps, p1;
-    m.range(Hp * Wp, p_per_block, p, ps, p1);
-    const float inv = 1.f / (float)(H * W);
-    float xa[8], xb[8], gam[8], bet[8], dsc[8], k0[8], k1[8], k2[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const float2 ms = stats[(size_t)n * C + c0 + k];
-        const float2 ss = S[(size_t)n * C + c0 + k];
-        xa[k] = ms.y; xb[k] = -ms.x * ms.y;
-        gam[k] = gamma[c0 + k]; bet[k] = beta[c0 + k];
-        dsc[k] = drop_scale(seed, site, n, c0 + k, drop_p);
-        k0[k] = gam[k] * ms.y;                            // out = k0*(dz - k1 - xh*k2); WS: k0*dz - (k1 + xh*k2)
-        k1[k] = ss.x * inv * (WS ? ms.y : 1.f);
-        k2[k] = ss.y * inv * (WS ? ms.y : 1.f);
-    }
-    const size_t img = (size_t)n * Hp * Wp;
-    const T* Gbase = G + img * ldc_G + coff_G + c0;
-    const T* rbase = raw + img * ldc_raw + coff_raw + c0;
-    T* dbase = draw + img * ldc_d + coff_d + c0;
+__device__ __forceinline__ void inact_apply_walk(const T* __restrict__ Gbase, const T* __restrict__ rbase, T* __restrict__ dbase, const float (&xa)[8],
+                                                 const float (&xb)[8], const float (&gam)[8], const float (&bet)[8], const float (&dsc)[8],
+                                                 const float (&k0)[8], const float (&k1)[8], const float (&k2)[8], int H, int W, int ldc_G,
+                                                 int ldc_raw, int ldc_d, int fold, int pm, int p, int ps, int p1) {
+    const int Hp = H + 2, Wp = W + 2;
     PixWalk w(p, ps, Wp);
     // fold != 0: `G` is the unit's single gradient source itself (pass 1 wrote no G): ring copies are folded onto the pixels they
     // copy here, exactly as pass 1 did (same order, same rounding), so both forms give the same bits
@@ -750,6 +736,115 @@ __global__ __launch_bounds__(256) void k_inact_bwd_apply(const T* __restrict__ G
     constexpr int U = FNET_EW_U;       // pixels per trip, all loads first
     for (; p + (U - 1) * ps < p1; p += U * ps) trip(IntC<U>{});
     for (; p < p1; p += ps) trip(IntC<1>{});
+}
+
+// ------------------------------------------------------------------ INACT_BWD_APPLY (pass 2)
+// d_raw = gamma*rstd*(dz - S1/HW - xhat*S2/HW) on the interior, 0 on the ring (so that d_raw can feed
+// the flattened dgrad / wgrad convolutions directly).
+// WS ("weighted sums", BatchNorm2d / GroupNorm): S holds what NORM_COMBINE_BWD made of the per-(n,c) sums -- their gamma-weighted
+// mean over the normalisation group -- and d_raw = gamma*rstd*dz - rstd*(S1'/HW + xhat*S2'/HW).
+template <typename T, int ACT, bool WS>
+__global__ __launch_bounds__(256) void k_inact_bwd_apply(const T* __restrict__ G, const T* __restrict__ raw, const float2* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                  const float2* __restrict__ S, T* __restrict__ draw, int H, int W, int C, int ldc_G, int coff_G, int ldc_raw,
+                                  int coff_raw, int ldc_d, int coff_d, int act, uint32_t site, uint32_t seed, float drop_p,
+                                  int p_per_block, int fold, int pm) {
+    const CgMap m(C);
+    if (!m.active) return;
+    const int n = blockIdx.y, Hp = H + 2, Wp = W + 2, c0 = m.cg * 8;
+    int p, ps, p1;
+    m.range(Hp * Wp, p_per_block, p, ps, p1);
+    const float inv = 1.f / (float)(H * W);
+    float xa[8], xb[8], gam[8], bet[8], dsc[8], k0[8], k1[8], k2[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float2 ms = stats[(size_t)n * C + c0 + k];
+        const float2 ss = S[(size_t)n * C + c0 + k];
+        xa[k] = ms.y; xb[k] = -ms.x * ms.y;
+        gam[k] = gamma[c0 + k]; bet[k] = beta[c0 + k];
+        dsc[k] = drop_scale(seed, site, n, c0 + k, drop_p);
+        k0[k] = gam[k] * ms.y;                            // out = k0*(dz - k1 - xh*k2); WS: k0*dz - (k1 + xh*k2)
+        k1[k] = ss.x * inv * (WS ? ms.y : 1.f);
+        k2[k] = ss.y * inv * (WS ? ms.y : 1.f);
+    }
+    const size_t img = (size_t)n * Hp * Wp;
+    const T* Gbase = G + img * ldc_G + coff_G + c0;
+    const T* rbase = raw + img * ldc_raw + coff_raw + c0;
+    T* dbase = draw + img * ldc_d + coff_d + c0;
+    inact_apply_walk<T, ACT, WS>(Gbase, rbase, dbase, xa, xb, gam, bet, dsc, k0, k1, k2, H, W, ldc_G, ldc_raw, ldc_d, fold, pm, p, ps, p1);
+}
+
+// ------------------------------------------------------------------ INACT_BWD_REDUCE + INACT_BWD_APPLY in one launch (small images)
+// The two passes of the norm / activation adjoint of a single-source unit as ONE kernel, on the same decomposition as k_stats_apply:
+// block = (image n, SA_CS-channel slice), 768 threads (the walks keep their 3- / 4-pixel trips: 140-170 registers).  Pass 1
+// (inact_reduce_walk) leaves S = (sum dz, sum dz * xhat) of the block's channels -- the whole image, so the sums are final in the block: they
+// are added to the S slab for AFFINE_GRAD_MULTI (one atomic per channel, onto the plan's zero) and stay in LDS for pass 2
+// (inact_apply_walk), which reads the gradient source and raw a second time from L2.  Replaces two launches of ~10 us fixed cost each.
+constexpr int SB_THREADS = 768;      // 12 waves = three per SIMD at 138 registers: what three co-resident blocks of the separate kernels reach
+template <typename T, int ACT, int SA_CS>
+__global__ __launch_bounds__(SB_THREADS) void k_inact_bwd_fused(const T* __restrict__ g1, const T* __restrict__ raw, const float2* __restrict__ stats,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ S,
+                                                                T* __restrict__ draw, int B, int H, int W, int C, int ldc_g1, int coff_g1, int ldc_raw,
+                                                                int coff_raw, int ldc_d, int coff_d, int fold, int pm, uint32_t site, uint32_t seed,
+                                                                float drop_p) {
+    constexpr int GROUPS = SA_CS / 8, PPI = SB_THREADS / GROUPS;
+    __shared__ float red[SB_THREADS / 64][GROUPS][16];
+    __shared__ float2 sums[SA_CS];
+    const int nslices = C / SA_CS, items = nslices * B, per = (items + 7) >> 3;
+    const int item = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= per || item >= items) return;            // (whole block: no barrier has been reached)
+    const int n = item / nslices, slice = item - n * nslices;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cg = tid & (GROUPS - 1), px = tid / GROUPS;
+    const int c0 = slice * SA_CS + cg * 8;
+    const int Hp = H + 2, Wp = W + 2, HW = H * W;
+    float xa[8], xb[8], gam[8], bet[8], dsc[8], s[8], t[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float2 ms = stats[(size_t)n * C + c0 + k];
+        xa[k] = ms.y; xb[k] = -ms.x * ms.y;
+        gam[k] = gamma[c0 + k]; bet[k] = beta[c0 + k];
+        dsc[k] = drop_scale(seed, site, n, c0 + k, drop_p);
+        s[k] = 0.f; t[k] = 0.f;
+    }
+    const size_t img = (size_t)n * Hp * Wp;
+    const T* rbase = raw + img * ldc_raw + coff_raw + c0;
+    const T* g1img = g1 + img * ldc_g1 + coff_g1 + c0;
+    T* dbase = draw + img * ldc_d + coff_d + c0;
+    inact_reduce_walk<T, ACT>(g1img, nullptr, rbase, nullptr, xa, xb, gam, bet, dsc, s, t, H, W, ldc_g1, 8, ldc_raw, 8, fold, 0, pm, px, PPI, HW);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+#pragma unroll
+        for (int d = GROUPS; d < 64; d <<= 1) {
+            s[k] += __shfl_xor(s[k], d);
+            t[k] += __shfl_xor(t[k], d);
+        }
+    }
+    if (lane < GROUPS) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { red[wave][lane][k] = s[k]; red[wave][lane][8 + k] = t[k]; }
+    }
+    __syncthreads();
+    if (tid < SA_CS) {
+        const int g = tid >> 3, k = tid & 7;
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < SB_THREADS / 64; ++wv) { a += red[wv][g][k]; b += red[wv][g][8 + k]; }
+        sums[tid] = make_float2(a, b);
+        float* Sp = S + ((size_t)n * C + slice * SA_CS + tid) * 2;
+        atomicAdd(Sp, a);
+        atomicAdd(Sp + 1, b);
+    }
+    __syncthreads();
+    const float inv = 1.f / (float)HW;
+    float k0[8], k1[8], k2[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float2 ss = sums[cg * 8 + k];
+        k0[k] = gam[k] * xa[k];
+        k1[k] = ss.x * inv;
+        k2[k] = ss.y * inv;
+    }
+    inact_apply_walk<T, ACT, false>(g1img, rbase, dbase, xa, xb, gam, bet, dsc, k0, k1, k2, H, W, ldc_g1, ldc_raw, ldc_d, fold, pm, px, PPI, Hp * Wp);
 }
 
 // ------------------------------------------------------------------ AFFINE_GRAD: dgamma += sum_n S2, dbeta += sum_n S1
@@ -1440,6 +1535,52 @@ int fnet_op_affine_grad_multi(const FnetOp& op, hipStream_t st) {
         if (u.C[j] > cmax) cmax = u.C[j];
     }
     hipLaunchKernelGGL(k_affine_grad_multi, dim3((cmax + 63) / 64, n), dim3(kThreads), 0, st, (const float*)op.p[0], (float*)op.p[1], u, B);
+    FNET_LAUNCH_CHECK();
+    return FNET_OK;
+}
+
+// INACT_BWD_REDUCE immediately followed by the INACT_BWD_APPLY of the same single-source InstanceNorm unit (no G, nothing pools S in
+// between), on a small image: one k_inact_bwd_fused launch instead of two.  Same contract as fnet_can_fuse_stats_apply.
+bool fnet_can_fuse_inact_bwd(const FnetOp& ro, const FnetOp& ao) {
+    static const bool on = [] { const char* e = getenv("FNET_FUSE_SMALL"); return !e || e[0] != '0'; }();
+    if (!on || ro.dtype != FNET_BF16 || ao.dtype != FNET_BF16 || ro.i[FNET_LANE_SLOT] != ao.i[FNET_LANE_SLOT]) return false;
+    for (int k = 0; k < 4; ++k)
+        if (ro.i[k] != ao.i[k]) return false;                       // B, H, W, C
+    const int B = ao.i[0], H = ao.i[1], W = ao.i[2], C = ao.i[3];
+    if (ro.p[1] || ro.p[6] || ro.p[8] || ro.p[9] || ao.i[15] != 0) return false;          // one source, no G, no in-kernel affine gradients, plain S
+    if (!ro.p[0] || ro.p[0] != ao.p[0] || ro.i[4] != ao.i[4] || ro.i[5] != ao.i[5]) return false;      // pass 2 reads the same gradient source
+    if (!ro.p[2] || ro.p[2] != ao.p[1] || ro.i[8] != ao.i[6] || ro.i[9] != ao.i[7]) return false;      // ... the same raw
+    if (!ro.p[3] || ro.p[3] != ao.p[2] || !ro.p[4] || ro.p[4] != ao.p[3] || !ro.p[5] || ro.p[5] != ao.p[4] || !ro.p[7] || ro.p[7] != ao.p[5] || !ao.p[6])
+        return false;
+    if (ro.i[14] != ao.i[10] || ro.i[15] != ao.i[14] || ro.i[16] != ao.i[11] || ro.i[17] != ao.i[12] || ro.f[0] != ao.f[0]) return false;
+    if ((ro.i[12] != 0) != (ao.i[13] != 0) || (ao.i[13] != 0 && ao.i[13] != 1)) return false;
+    // (<= 32^2 only: at 64^2 the fused launch measured the same as the two -- 52.6 against 51.6 us, 86.6 against 82.8 -- these passes are
+    // bound by their arithmetic there, not by launch costs; FNET_SB_MAXHW = the image side, tuning knob)
+    const char* esb = getenv("FNET_SB_MAXHW");              // (read per call: the kernel tests raise it to cover 64^2)
+    const long long sbv = esb ? atoll(esb) : 32, sb_max = (sbv + 2) * (sbv + 2);
+    if (B <= 0 || H < 2 || W < 2 || C % 16 != 0 || (long long)(H + 2) * (W + 2) > sb_max) return false;
+    if (!vec_ok((void*)ao.p[0], ao.i[4], ao.i[5], C, ao.dtype) || !vec_ok((void*)ao.p[1], ao.i[6], ao.i[7], C, ao.dtype) ||
+        !vec_ok((void*)ao.p[6], ao.i[8], ao.i[9], C, ao.dtype))
+        return false;
+    if (ao.i[10] < 0 || ao.i[10] > 4 || ao.i[14] < 0 || ao.i[14] > 3 || !(ao.f[0] >= 0.f && ao.f[0] < 1.f) || !cg_ok(C, B)) return false;
+    return off_ok(H, W, ao.i[4], ao.i[6], ao.i[8]) && (long long)B * (C / 16) < (1ll << 30);
+}
+int fnet_op_inact_bwd_fused(const FnetOp& ro, const FnetOp& op, hipStream_t st) {
+    FNET_CHECK_ARG(fnet_can_fuse_inact_bwd(ro, op));
+    const int B = op.i[0], H = op.i[1], W = op.i[2], C = op.i[3];
+    const char* ecs = getenv("FNET_SA_CS");
+    const int forced_cs = ecs ? atoi(ecs) : 0;
+    int cs = (C % 64 == 0 && (long long)B * (C / 64) >= 256) ? 64 : (C % 32 == 0 && (long long)B * (C / 32) >= 256) ? 32 : 16;
+    if (forced_cs == 16 || (forced_cs == 32 && C % 32 == 0) || (forced_cs == 64 && C % 64 == 0)) cs = forced_cs;
+    const int items = B * (C / cs);
+    using T = bf16_t;
+#define FNET_SB_LAUNCH(CS_)                                                                                                                    \
+    DISPATCH_ACT(op.i[10], hipLaunchKernelGGL((k_inact_bwd_fused<T, ACT, CS_>), dim3((items + 7) / 8 * 8), dim3(SB_THREADS), 0, st,              \
+                                              (const T*)op.p[0], (const T*)op.p[1], (const float2*)op.p[2], (const float*)op.p[3],             \
+                                              (const float*)op.p[4], (float*)op.p[5], (T*)op.p[6], B, H, W, C, op.i[4], op.i[5], op.i[6],       \
+                                              op.i[7], op.i[8], op.i[9], op.i[13], op.i[14], (uint32_t)op.i[11], (uint32_t)op.i[12], op.f[0]))
+    if (cs == 64) { FNET_SB_LAUNCH(64); } else if (cs == 32) { FNET_SB_LAUNCH(32); } else { FNET_SB_LAUNCH(16); }
+#undef FNET_SB_LAUNCH
     FNET_LAUNCH_CHECK();
     return FNET_OK;
 }

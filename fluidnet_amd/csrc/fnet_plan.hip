@@ -159,6 +159,10 @@ int fnet_plan_run(const FnetOp* ops, int32_t n_ops, void* stream, int32_t* faile
                        fnet_can_fuse_stats_apply(ops[k], ops[k + 1])) {
                 rc = fnet_op_stats_apply(ops[k], ops[k + 1], st);      // one launch for the pair (small images)
                 if (rc == FNET_OK) ++k;
+            } else if (ops[k].op == FNET_OP_INACT_BWD_REDUCE && k + 1 < n_ops && ops[k + 1].op == FNET_OP_INACT_BWD_APPLY &&
+                       fnet_can_fuse_inact_bwd(ops[k], ops[k + 1])) {
+                rc = fnet_op_inact_bwd_fused(ops[k], ops[k + 1], st);  // both adjoint passes of a single-source unit in one launch (small images)
+                if (rc == FNET_OK) ++k;
             } else if (ops[k].op == FNET_OP_PREP_WEIGHTS && k + 1 < n_ops && ops[k + 1].op == FNET_OP_PREP_WEIGHTS && prep_batching) {
                 // a run of weight re-layouts (the start of every training step) goes out as one launch per 32 records
                 int32_t m = 1;

@@ -30,3 +30,23 @@ for (H, C) in ((128, 32), (128, 64), (64, 64), (64, 128), (32, 128), (32, 256), 
         out.append(f"{name} {t.elapsed_ms() / 50 * 1e3:6.1f} us")
     mb = 64 * (H + 2) * (H + 2) * C * 2 / 1e6
     print(f"{H}x{H} C={C} ({mb:5.1f} MB per tensor): " + " | ".join(out), flush=True)
+
+from test_gpu_fused_small import _mk_bwd
+
+print("adjoint pair (INACT_BWD_REDUCE + INACT_BWD_APPLY, single source):")
+for (H, C) in ((128, 64), (64, 64), (64, 128), (32, 128), (32, 256), (16, 256)):
+    pb, ops, S, draw = _mk_bwd(64, H, H, C, C, 0, 1, "gelu", 1, 0.1)
+    arr = lower(pb, ops)
+    out = []
+    for name, chunks in (("fused", [arr]), ("separate", [arr[0:1], arr[1:2]])):
+        for _ in range(3):
+            for c in chunks:
+                rt.run_ops(c)
+        t = rt.Timer()
+        t.start()
+        for _ in range(50):
+            for c in chunks:
+                rt.run_ops(c)
+        t.stop()
+        out.append(f"{name} {t.elapsed_ms() / 50 * 1e3:6.1f} us")
+    print(f"{H}x{H} C={C}: " + " | ".join(out), flush=True)

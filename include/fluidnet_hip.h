@@ -146,6 +146,12 @@ int fnet_device_info(int32_t out[4]);
  * (ml/training/trainer.py:190-195) and the rollout loop body (ml/scripts/simple_infer.py:226-260).
  * Every op validates its arguments on the host before launching; on the first failure nothing
  * further is launched and *failed_index (if non-null) receives the op index.
+ * The executor may issue adjacent records as one launch where that is the same computation: a run of PREP_WEIGHTS records (one launch
+ * per 32), IN_STATS immediately followed by the APPLY of the same InstanceNorm unit on an image of at most 64 x 64, and
+ * INACT_BWD_REDUCE immediately followed by the INACT_BWD_APPLY of the same single-source unit on at most 32 x 32 (ml/models/unet.py:65-69
+ * and its autograd adjoint in one kernel each; statistics summed in a fixed order, outputs within one bf16 ulp of the separate
+ * launches).  Records that do not qualify, or that would fail their own checks, take the ordinary launchers; results and error
+ * reporting are otherwise those of record-by-record execution.
  */
 int fnet_plan_run(const FnetOp* ops, int32_t n_ops, void* stream, int32_t* failed_index);
 /* The hipStream_t behind side lane `lane` (1 .. FNET_MAX_LANES-1) of the current device, created on first use and owned by the

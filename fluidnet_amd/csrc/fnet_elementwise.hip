@@ -1394,6 +1394,12 @@ static long long sa_max_pixels() {       // padded pixels per image up to which 
     static const long long v = [] { const char* e = getenv("FNET_SA_MAXHW"); const long long s = e ? atoll(e) : 64; return (s + 2) * (s + 2); }();
     return v;
 }
+static bool sa_enough_items(int B, int C) {
+    const char* e = getenv("FNET_SA_MINITEMS");               // (read per call: the kernel tests, which use small batches, set it to 1)
+    // (96: K2 256^2 B = 32 gains with 128 blocks, 823 against 802 samples/s; a batch-1 frame -- 4 to 16 blocks -- loses)
+    const long long need = e ? atoll(e) : 96, items = (long long)B * (C / 16);
+    return items >= need && items < (1ll << 30);
+}
 bool fnet_can_fuse_stats_apply(const FnetOp& so, const FnetOp& ao) {
     static const bool on = [] { const char* e = getenv("FNET_FUSE_SMALL"); return !e || e[0] != '0'; }();
     if (!on || so.dtype != FNET_BF16 || ao.dtype != FNET_BF16 || so.i[FNET_LANE_SLOT] != ao.i[FNET_LANE_SLOT]) return false;
@@ -1406,7 +1412,9 @@ bool fnet_can_fuse_stats_apply(const FnetOp& so, const FnetOp& ao) {
         !vec_ok((void*)ao.p[5], ao.i[8], ao.i[9], C, ao.dtype))
         return false;
     if (ao.i[10] < 0 || ao.i[10] > 4 || ao.i[11] < 0 || ao.i[11] > 3 || !(ao.f[0] >= 0.f && ao.f[0] < 1.f) || !cg_ok(C, B)) return false;
-    return off_ok(H, W, ao.i[4], ao.p[4] ? ao.i[6] : 8, ao.i[8]) && (long long)B * (C / 16) < (1ll << 30);
+    // one block per (image, slice): worth it only with enough blocks (a batch-1 rollout frame keeps the separate launches: 0.83 against
+    // 0.89 ms per frame)
+    return off_ok(H, W, ao.i[4], ao.p[4] ? ao.i[6] : 8, ao.i[8]) && sa_enough_items(B, C);
 }
 int fnet_op_stats_apply(const FnetOp& so, const FnetOp& op, hipStream_t st) {
     FNET_CHECK_ARG(fnet_can_fuse_stats_apply(so, op));
@@ -1563,7 +1571,7 @@ bool fnet_can_fuse_inact_bwd(const FnetOp& ro, const FnetOp& ao) {
         !vec_ok((void*)ao.p[6], ao.i[8], ao.i[9], C, ao.dtype))
         return false;
     if (ao.i[10] < 0 || ao.i[10] > 4 || ao.i[14] < 0 || ao.i[14] > 3 || !(ao.f[0] >= 0.f && ao.f[0] < 1.f) || !cg_ok(C, B)) return false;
-    return off_ok(H, W, ao.i[4], ao.i[6], ao.i[8]) && (long long)B * (C / 16) < (1ll << 30);
+    return off_ok(H, W, ao.i[4], ao.i[6], ao.i[8]) && sa_enough_items(B, C);
 }
 int fnet_op_inact_bwd_fused(const FnetOp& ro, const FnetOp& op, hipStream_t st) {
     FNET_CHECK_ARG(fnet_can_fuse_inact_bwd(ro, op));

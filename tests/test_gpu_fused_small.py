@@ -12,6 +12,14 @@ from fluidnet_amd.engine.plan import PlanBuilder, Ref, lower
 from helpers import tiny_cfg
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _fuse_small_batches(monkeypatch):
+    # the library fuses only where B * C / 16 >= 96 (enough blocks); these kernel tests use small batches
+    monkeypatch.setenv("FNET_SA_MINITEMS", "1")
+
+
 ACTS = {"relu": 0, "leaky": 1, "gelu": 2, "silu": 3}
 CASES = [
     # B, H,  W,  C,  ldc_raw, coff_raw, residual, act,     pm, drop_p
@@ -83,6 +91,16 @@ def test_fused_stats_apply_equals_separate_launches(case, cs, monkeypatch):
     # run to run: the fused launch is deterministic
     s3, d3 = _run(arr, st, dst, together=True)
     assert torch.equal(s2, s3) and torch.equal(d2, d3)
+
+
+def test_small_batches_do_not_fuse(monkeypatch):
+    # B * C / 16 = 2 * 4 < 96: the pair runs as its separate launches inside one call too -> bit-identical to one call per record
+    monkeypatch.delenv("FNET_SA_MINITEMS")
+    pb, ops, st, dst = _mk(2, 32, 32, 64, 64, 0, False, "gelu", 1, 0.0)
+    arr = lower(pb, ops)
+    s1, d1 = _run(arr, st, dst, together=False)
+    s2, d2 = _run(arr, st, dst, together=True)
+    assert torch.equal(s1, s2) and torch.equal(d1, d2)
 
 
 def test_large_images_and_foreign_pairs_do_not_fuse():

@@ -180,19 +180,38 @@ def profile_ops(plan_arrays, recs_by_section, dump_path=None):
         tm[1].stop()
         empty.append(tm[1].elapsed_ms())
     overhead = min(empty)
+    # a unit's statistics + normalise / activate records, and its two adjoint passes, are timed TOGETHER (one fnet_plan_run call): the
+    # executor issues such a pair as one fused launch on small images, which a record-by-record timing would never see.  The pair's
+    # algorithmic bytes are those of its second record (+ a materialised G): what an ideal fusion moves.
+    PAIRS = {("IN_STATS", "APPLY"): "NORM_ACT_FWD", ("INACT_BWD_REDUCE", "INACT_BWD_APPLY"): "NORM_ACT_BWD"}
     for name, arr in plan_arrays.items():
         recs = recs_by_section[name]
-        for k in range(len(arr)):
+        k = -1
+        while k + 1 < len(arr):
+            k += 1
             t = tm[0]
-            one = arr[k:k + 1].copy()
+            r = recs[k]
+            kind = rt.OPNAME[r.code]
+            pair = PAIRS.get((kind, rt.OPNAME[recs[k + 1].code])) if k + 1 < len(arr) else None
+            one = arr[k:k + (2 if pair else 1)].copy()
             one["i"][:, rt.LANE_SLOT] = 0          # per-op timing: side-lane launches are timed on the caller's stream too
             t.start()
             rt.run_ops(one)
             t.stop()
             ms = max(t.elapsed_ms() - overhead, 0.0)
-            r = recs[k]
-            kind = rt.OPNAME[r.code]
             if kind.startswith("EVENT_"):          # lane bookkeeping, not a kernel
+                continue
+            if pair:
+                r2 = recs[k + 1]
+                rows.append((name, k, pair, r2.tag, ms, 0.0, list(r.i[:12])))
+                esz = 2 if r2.dtype == rt.BF16 else 4
+                a = agg.setdefault(pair, {"ms": 0.0, "n": 0, "flops": 0.0, "bytes": 0.0})
+                a["ms"] += ms
+                a["n"] += 1
+                a["bytes"] += hbm_bytes(rt.OPNAME[r2.code], r2, esz)
+                if pair == "NORM_ACT_BWD" and len(r.p) > 6 and r.p[6] is not None:
+                    a["bytes"] += r.i[0] * r.i[1] * r.i[2] * r.i[3] * esz          # G out
+                k += 1
                 continue
             rows.append((name, k, kind, r.tag, ms, r.flops, list(r.i[:12])))
             if kind == "CONV3X3":

@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """Headline benchmark: K4 UNet_medium 128^2 rollout-training samples/s (BASELINE.json metric, config[1]).
 
-    python bench.py --gpus N --steps K --warmup W            (N>1: launched by torch.distributed.run, one rank per GPU)
-    python bench.py --mode rollout                            (600-frame 256^2 x 64-scene inference rollout, frames/s)
+    python bench.py --gpus N --steps K --warmup W            (N>1: one rank per GPU over RCCL; started by torch.distributed.run, or --
+                                                              when no launcher set WORLD_SIZE -- by this script itself, which then only
+                                                              spawns N children, relays rank 0's line and never touches the GPU)
+    python bench.py --mode rollout                            (600-frame 256^2 x 64-scene inference rollout alone, frames/s)
 
 A step = one pass of the hot path over one synthetic batch resident in HBM: K UNet forwards + physics losses, BPTT
 backward, (RCCL gradient all-reduce), clip + Adam.  Prints ONE JSON line on rank 0.
@@ -27,13 +29,13 @@ from fluidnet_amd.engine import runtime as rt  # noqa: E402
 from fluidnet_amd.engine.rollout_plan import RolloutInferPlan  # noqa: E402
 from fluidnet_amd.engine.train_plan import RolloutTrainPlan  # noqa: E402
 from fluidnet_amd.models.unet import UNet, UNetConfig  # noqa: E402
-from fluidnet_amd.training.dp import dp_train_step, torch_all_reduce  # noqa: E402
+from fluidnet_amd.training import launch  # noqa: E402
+from fluidnet_amd.training.dp import ExchangeProbe, dp_train_step, torch_all_reduce  # noqa: E402
 from fluidnet_amd.training.physics_loss import PhysicsAwareLoss  # noqa: E402
 from fluidnet_amd.training.trainer import step_seed  # noqa: E402
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0      # MI355X dense bf16 (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0               # MI355X HBM3E (MI355X_MICROARCH.md: ~8 TB/s)
-HBM_PEAK_GBS = 8000.0
 
 
 # the reference's shipped architectures (ml/config/model_architectures/*.yaml); the headline metric is quoted on UNet_medium
@@ -139,9 +141,12 @@ class TrainStepper:
         # batch formation inside the step: a new batch per step from the HBM-resident store (K = 1 plans take the masks of frame t)
         self.loader = synthetic_store(R, K, world, rank, B) if loader else None
         self._batches, self._epoch = [], 0
+        self.probe = None
         if world > 1:
             import torch.distributed as dist
             self.dist = dist
+            self.probe = ExchangeProbe(use_events=dist.get_backend() == "nccl")
+            self.all_reduce = torch_all_reduce(dist, self.probe)
             if dist.get_backend() == "gloo":            # rehearsal mode: through the host
                 h = self.model.flat_params.detach().cpu()
                 dist.broadcast(h, 0)
@@ -164,7 +169,32 @@ class TrainStepper:
             self.next_batch()
         p.set_adam_scalars(self.lr, self.t)
         p.set_dropout_seed(step_seed(self.t, self.rank))
-        dp_train_step(p, self.world, torch_all_reduce(self.dist) if self.world > 1 else None)
+        dp_train_step(p, self.world, self.all_reduce if self.world > 1 else None, probe=self.probe)
+
+    def exchange_alone_ms(self, iters=10):
+        """The step's exchange by itself, nothing to hide behind: the K fluid counts + the gradient buckets all-reduced `iters` times
+        between two events on the current stream (ranks aligned by a barrier first).  Next to `allreduce_exposed_ms` it says how much
+        of the exchange the backward pass covered."""
+        p, g = self.plan, self.plan.pb.grads.tensor
+        keep = g.clone()
+        ar = torch_all_reduce(self.dist)
+        barrier(self.world)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        for _ in range(iters):
+            hs = [ar(p.gcnt.tensor, "sum")]
+            for _end, (lo, hi), _lane in p.grad_buckets:
+                if hi > lo:
+                    hs.append(ar(g[lo:hi], "avg"))
+            for h in hs:
+                if h is not None:
+                    h.wait()
+        e1.record()
+        torch.cuda.synchronize()
+        host = (time.perf_counter() - t0) * 1e3 / iters
+        g.copy_(keep)
+        return (e0.elapsed_time(e1) / iters) if self.dist.get_backend() == "nccl" else host
 
 
 def profile_ops(plan_arrays, recs_by_section, dump_path=None):
@@ -392,11 +422,11 @@ def measure_rollout(a, R, batch, frames, warm, world, rank, profile=True, dump=N
     plan.step(frames)
     barrier(world)
     dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
     if world > 1:
         import torch.distributed as dist
+        tmax = torch.tensor([dt], device="cuda" if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+        dt = float(tmax.item())
     value = world * batch * frames / dt
     fl = sum(r.flops for r in plan.frame)
     out = {"metric": "rollout frames/sec", "value": round(value, 1), "unit": "scene-frames/s", "n_gpus": world, "steps": frames,
@@ -424,6 +454,93 @@ def measure_rollout(a, R, batch, frames, warm, world, rank, profile=True, dump=N
     return out
 
 
+def measure_train(a, arch, depth, B, R, K, steps, warm, world, rank, loader=True, profile=True, dump=None, headline=False):
+    """`steps` timed optimisation steps of one training configuration (after `warm` untimed ones); returns (JSON object, stepper)."""
+    st = TrainStepper(B, R, K, a.precision, world, rank, conv_impl=a.conv_impl, arch=arch, depth=depth, loader=loader)
+    for _ in range(warm):
+        st.step()
+    if st.probe is not None:
+        st.probe = st.probe.__class__(st.probe.use_events)          # count the exchange over the timed steps only
+        st.all_reduce = torch_all_reduce(st.dist, st.probe)
+    barrier(world)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        st.step()
+    barrier(world)
+    dt_rank = time.perf_counter() - t0
+    dt = dt_rank
+    if world > 1:
+        tmax = torch.tensor([dt], device="cuda" if st.dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
+        st.dist.all_reduce(tmax, op=st.dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    loss = st.plan.loss_dict()
+    value = world * B * steps / dt
+    out = {"metric": "train samples/sec (K4 UNet 128^2)" if (K == 4 and R == 128 and arch == "medium" and depth is None) else
+           f"train samples/sec (K{K} UNet_{arch} {R}^2)",
+           "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": steps, "warmup": warm,
+           "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": a.precision, "data": "synthetic",
+           "config": {"workload": f"UNet_{arch}{'' if depth is None else f' depth {depth}'} K{K} rollout training {R}x{R}, batch {B}/GPU, MSE+divergence+gradient+emitter, "
+                                  f"BPTT through all K, clip 1.0 + Adam, dropout {st.model.cfg.dropout}; "
+                                  + ("a new batch per step gathered (flip augmentation included) from the HBM-resident store" if st.loader is not None
+                                     else "one static resident batch"), "global_batch": B * world,
+                      "parallelism": f"dp{world}", "final_loss": round(loss["total"], 6),
+                      "hbm_bytes_allocated": st.bytes}}
+    flops_step = sum(r.flops for s in st.plan.sections.values() for r in s)
+    out["config"]["algorithmic_tflop_per_step"] = round(flops_step * world / 1e12, 4)          # whole job (all ranks), like `value`
+    out["config"]["end_to_end_tflops"] = round(flops_step * world * steps / dt / 1e12, 2)
+    if world > 1:
+        out["exchange"] = exchange_report(st, B, steps, dt_rank, rank, world)
+    if rank == 0 and profile:
+        agg = profile_ops(st.plan._lowered, st.plan.sections, dump)
+        tot = sum(v["ms"] for v in agg.values())
+        conv = agg.get("CONV3X3_MFMA") or agg.get("CONV3X3_REF")
+        ach = conv["flops"] / (conv["ms"] * 1e-3) / 1e12
+        traffic, src = pmc_traffic("k_conv3x3_dma") if headline else (None, None)
+        out["roofline"] = {"bound": "mfma", "kernel": "k_conv3x3_dma (forward + data-gradient launches)",
+                           "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                           "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": src,
+                           "launches_per_step": conv["n"], "avg_launch_ms": round(conv["ms"] / conv["n"], 4),
+                           "algorithmic_gflop_per_launch": round(conv["flops"] / conv["n"] / 1e9, 3),
+                           "algorithmic_bytes_per_launch": round(conv["bytes"] / conv["n"])}
+        if headline:
+            out["roofline"]["reference_gemm"] = reference_gemm()
+        hb = hbm_roofline(agg)
+        if hb:
+            out["hbm_roofline"] = hb
+        out["breakdown_ms_per_step"] = {k: round(v["ms"], 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
+        out["breakdown_ms_per_step"]["_sum"] = round(tot, 3)
+        wg = agg.get("WGRAD_MFMA")
+        if wg:
+            out["wgrad_tflops"] = round(wg["flops"] / (wg["ms"] * 1e-3) / 1e12, 2)
+    return out, st
+
+
+def exchange_report(st, B, steps, dt_rank, rank, world):
+    """What lets a reader of an N > 1 line check that the collective library really saw N ranks and what the exchange cost: backend and
+    world size as torch.distributed reports them, every rank's device and own samples/s, the exchange timed alone and the part of it
+    that the compute stream had to wait for in the timed steps.  Collective on all ranks; rank 0 keeps the result."""
+    dist = st.dist
+    me = {"rank": rank, "device_index": torch.cuda.current_device(), "device_name": torch.cuda.get_device_name(),
+          "pid": os.getpid(), "samples_per_s": round(B * steps / dt_rank, 2),
+          "allreduce_exposed_ms": round(st.probe.exposed_ms() / max(st.probe.steps, 1), 4)}
+    ranks = [None] * world
+    dist.all_gather_object(ranks, me)
+    alone = st.exchange_alone_ms()
+    g = st.plan.pb.grads.tensor
+    sps = [r["samples_per_s"] for r in ranks]
+    return {"backend": dist.get_backend(), "library": "RCCL (torch.distributed backend nccl on ROCm)" if dist.get_backend() == "nccl"
+            else "gloo through the host (rehearsal mode, FNET_DIST_BACKEND=gloo: ranks may share a device; not a scaling figure)",
+            "rccl_world": dist.get_world_size() if dist.get_backend() == "nccl" else None, "world": dist.get_world_size(),
+            "buckets": [{"elements": hi - lo, "lane": lane} for _e, (lo, hi), lane in st.plan.grad_buckets if hi > lo],
+            "gradient_bytes": int(g.numel() * g.element_size()),
+            "allreduce_ms_per_step": round(alone, 4), "allreduce_exposed_ms": max(r["allreduce_exposed_ms"] for r in ranks),
+            "rank_samples_per_s_min": min(sps), "rank_samples_per_s_max": max(sps), "ranks": ranks}
+
+
+C4_LEGS = (("K2 256x256 depth 4", dict(K=2, R=256, depth=4, B=32)), ("K2 512x512 depth 5", dict(K=2, R=512, depth=5, B=8)))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -438,16 +555,22 @@ def main():
     ap.add_argument("--precision", default="bf16")
     ap.add_argument("--conv-impl", default="auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-rollout", action="store_true", help="skip the short 256^2 x 64-scene rollout leg of the default training line")
+    ap.add_argument("--no-rollout", action="store_true", help="skip the 600-frame 256^2 x 64-scene rollout leg of the default training line")
+    ap.add_argument("--rollout-frames", type=int, default=600, help="frames of the default line's rollout leg (BASELINE config 5: 600)")
+    ap.add_argument("--no-config4", action="store_true", help="skip the two short K2 256^2 / 512^2 legs (BASELINE config 4) of the default line")
     ap.add_argument("--static-batch", action="store_true", help="reuse one resident batch instead of gathering a new one per step from the HBM-resident store")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--dump-ops", default=None, help="write per-op HIP-event timings of the instrumented step to this CSV")
+    ap.add_argument("--spawn-timeout", type=float, default=1500.0, help="time limit (s) for the ranks this script starts itself")
     a = ap.parse_args()
+    if launch.needs_spawn(a.gpus):
+        # un-launched N-rank run: this process only starts the ranks (it has made no torch.cuda / HIP call and makes none)
+        sys.exit(launch.main_spawn(os.path.abspath(__file__), sys.argv[1:], a.gpus, a.spawn_timeout))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); fluidnet_amd has no CPU path")
     rank, world, local = dist_setup(a.gpus)
     if world != a.gpus:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: a launcher must start exactly --gpus ranks")
     rt.lib()
 
     if a.mode == "train":
@@ -455,72 +578,38 @@ def main():
         steps = a.steps if a.steps is not None else 10
         warm = a.warmup if a.warmup is not None else 3
         default_line = a.k == 4 and R == 128 and a.batch == 64 and a.precision == "bf16" and a.arch == "medium" and a.depth is None
-        st = TrainStepper(a.batch, R, a.k, a.precision, world, rank, conv_impl=a.conv_impl, arch=a.arch, depth=a.depth, loader=not a.static_batch)
-        for _ in range(warm):
-            st.step()
-        barrier(world)
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            st.step()
-        barrier(world)
-        dt = time.perf_counter() - t0
-        tmax = torch.tensor([dt], device="cuda" if world == 1 or st.dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
-        if world > 1:
-            st.dist.all_reduce(tmax, op=st.dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-        loss = st.plan.loss_dict()
-        ms_step = dt / steps * 1e3
-        value = world * a.batch * steps / dt
-        out = {"metric": "train samples/sec (K4 UNet 128^2)" if (a.k == 4 and R == 128 and a.arch == "medium") else
-               f"train samples/sec (K{a.k} UNet_{a.arch} {R}^2)",
-               "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": steps, "warmup": warm,
-               "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": a.precision, "data": "synthetic",
-               "config": {"workload": f"UNet_{a.arch}{'' if a.depth is None else f' depth {a.depth}'} K{a.k} rollout training {R}x{R}, batch {a.batch}/GPU, MSE+divergence+gradient+emitter, "
-                                      f"BPTT through all K, clip 1.0 + Adam, dropout {st.model.cfg.dropout}; "
-                                      + ("a new batch per step gathered (flip augmentation included) from the HBM-resident store" if st.loader is not None
-                                         else "one static resident batch"), "global_batch": a.batch * world,
-                          "parallelism": f"dp{world}", "final_loss": round(loss["total"], 6),
-                          "hbm_bytes_allocated": st.bytes}}
-        flops_step = sum(r.flops for s in st.plan.sections.values() for r in s)
-        out["config"]["algorithmic_tflop_per_step"] = round(flops_step * world / 1e12, 4)          # whole job (all ranks), like `value`
-        out["config"]["end_to_end_tflops"] = round(flops_step * world * steps / dt / 1e12, 2)
-        if rank == 0 and not a.no_profile:
-            agg = profile_ops(st.plan._lowered, st.plan.sections, a.dump_ops)
-            tot = sum(v["ms"] for v in agg.values())
-            conv = agg.get("CONV3X3_MFMA") or agg.get("CONV3X3_REF")
-            ach = conv["flops"] / (conv["ms"] * 1e-3) / 1e12
-            default_wl = a.k == 4 and R == 128 and a.batch == 64 and a.precision == "bf16" and a.arch == "medium"
-            traffic, src = pmc_traffic("k_conv3x3_dma") if default_wl else (None, None)
-            out["roofline"] = {"bound": "mfma", "kernel": "k_conv3x3_dma (forward + data-gradient launches)",
-                               "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": src,
-                               "launches_per_step": conv["n"], "avg_launch_ms": round(conv["ms"] / conv["n"], 4),
-                               "algorithmic_gflop_per_launch": round(conv["flops"] / conv["n"] / 1e9, 3),
-                               "algorithmic_bytes_per_launch": round(conv["bytes"] / conv["n"])}
-            if default_wl:
-                out["roofline"]["reference_gemm"] = reference_gemm()
-            hb = hbm_roofline(agg)
-            if hb:
-                out["hbm_roofline"] = hb
-            out["breakdown_ms_per_step"] = {k: round(v["ms"], 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
-            out["breakdown_ms_per_step"]["_sum"] = round(tot, 3)
-            wg = agg.get("WGRAD_MFMA")
-            if wg:
-                out["wgrad_tflops"] = round(wg["flops"] / (wg["ms"] * 1e-3) / 1e12, 2)
+        out, st = measure_train(a, a.arch, a.depth, a.batch, R, a.k, steps, warm, world, rank, loader=not a.static_batch,
+                                profile=not a.no_profile, dump=a.dump_ops, headline=default_line)
+        del st
+        torch.cuda.empty_cache()
         if rank == 0 and world == 1 and not a.no_cpu_baseline and a.arch == "medium":
             out["cpu_baseline"] = cpu_baseline_train(a.k, R)
         if default_line and not a.no_rollout:
             # the second half of BASELINE.json's metric ("rollout frames/sec", config 5) in the same line: 64 scenes at 256^2, the
-            # hipGraph-captured frame replayed 120 times after 10 warm-up frames (python bench.py --mode rollout runs all 600)
-            del st
-            torch.cuda.empty_cache()
-            ro = measure_rollout(a, 256, 64, 120, 10, world, rank, profile=not a.no_profile)
+            # hipGraph-captured frame replayed 600 times after 10 warm-up frames
+            ro = measure_rollout(a, 256, 64, a.rollout_frames, 10, world, rank, profile=not a.no_profile)
             if rank == 0:
                 out["rollout"] = {"metric": ro["metric"], "value": ro["value"], "unit": ro["unit"], "frames": ro["steps"], "scenes_per_gpu": 64,
                                   "resolution": 256, "ms_per_frame_step": ro["ms_per_step"], "state_finite": ro["config"]["state_finite"],
                                   "conv_tflops": ro.get("roofline", {}).get("achieved"), "conv_frac": ro.get("roofline", {}).get("frac"),
                                   "hbm_gb_per_s": ro.get("hbm_roofline", {}).get("achieved"), "hbm_frac": ro.get("hbm_roofline", {}).get("frac")}
+            torch.cuda.empty_cache()
+        if default_line and not a.no_config4:
+            # BASELINE config 4 under the same clock: K2 at 256^2 / 512^2 with the deeper encoders, 3 warm-up + 5 timed steps each
+            legs = {}
+            for name, c in C4_LEGS:
+                o4, st4 = measure_train(a, "medium", c["depth"], c["B"], c["R"], c["K"], 5, 3, world, rank, loader=True,
+                                        profile=not a.no_profile)
+                del st4
+                torch.cuda.empty_cache()
+                if rank == 0:
+                    legs[name] = {"metric": o4["metric"], "value": o4["value"], "unit": o4["unit"], "ms_per_step": o4["ms_per_step"],
+                                  "steps": 5, "warmup": 3, "batch_per_gpu": c["B"], "workload": o4["config"]["workload"],
+                                  "end_to_end_tflops": o4["config"]["end_to_end_tflops"],
+                                  "conv_tflops": o4.get("roofline", {}).get("achieved"), "conv_frac": o4.get("roofline", {}).get("frac"),
+                                  "hbm_gb_per_s": o4.get("hbm_roofline", {}).get("achieved"), "final_loss": o4["config"]["final_loss"]}
+            if rank == 0:
+                out["config4"] = legs
     else:
         R = a.res or 256
         frames = a.steps if a.steps is not None else 600

@@ -17,6 +17,7 @@ Clip-norm + Adam then run identically on every rank on the averaged gradient.
 """
 from __future__ import annotations
 
+import time
 from typing import Callable, List, Optional
 
 import torch
@@ -33,8 +34,39 @@ def fluid_counts(plan) -> torch.Tensor:
     return ((sel[:, :, 0] == 0) & (sel[:, :, 1] == 0)).sum(dim=(0, 2, 3)).to(torch.float64)
 
 
+class ExchangeProbe:
+    """Measures what the exchange costs the step (bench.py's `allreduce_exposed_ms`): HIP events on the CURRENT stream right before and
+    right after the stream is made to wait for the pending collectives.  The first event completes when everything the step queued before
+    the wait has run, the second when the collectives have landed too, so their distance is the time the compute stream stood still for
+    the exchange -- 0 when the all-reduce was hidden behind the backward pass.  Host-side collectives (gloo rehearsal) block the host
+    instead; their wall time is accumulated as `host_ms`.  Events are read once, after the timed region (`exposed_ms`)."""
+
+    def __init__(self, use_events: bool):
+        self.use_events = use_events
+        self.pairs: List = []
+        self.host_ms = 0.0
+        self.steps = 0
+
+    def before_wait(self):
+        if not self.use_events:
+            return None
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def after_wait(self, e0) -> None:
+        if e0 is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            self.pairs.append((e0, e1))
+
+    def exposed_ms(self) -> float:
+        """Total stall (ms) over the probed steps; call after a device synchronisation."""
+        return float(sum(a.elapsed_time(b) for a, b in self.pairs)) + self.host_ms
+
+
 def dp_train_step(plan, world: int, all_reduce: Optional[Callable] = None, run: Optional[Callable] = None, avg: bool = True,
-                  run_slice: Optional[Callable] = None) -> None:
+                  run_slice: Optional[Callable] = None, probe: Optional[ExchangeProbe] = None) -> None:
     """One optimisation step of `plan` (RolloutTrainPlan built with world=world) whose x0 / y / masks are already loaded.
 
     all_reduce(tensor, op, stream=None) with op in {"sum", "avg"} reduces in place across ranks and returns None or a handle
@@ -54,7 +86,7 @@ def dp_train_step(plan, world: int, all_reduce: Optional[Callable] = None, run: 
     plan.gcnt.tensor.copy_(fluid_counts(plan))
     pending.append(all_reduce(plan.gcnt.tensor, "sum"))         # overlaps the forward pass
     run("fwd")
-    _wait(pending)
+    _wait(pending, probe)
     run("fin")
     g = plan.pb.grads.tensor
     a = 0
@@ -63,27 +95,43 @@ def dp_train_step(plan, world: int, all_reduce: Optional[Callable] = None, run: 
         a = end
         if hi > lo:
             pending.append(all_reduce(g[lo:hi], "avg" if avg else "sum", stream=rt.lane_stream(lane) if (lane and g.is_cuda) else None))
-    _wait(pending)
+    _wait(pending, probe)
     run("opt")
+    if probe is not None:
+        probe.steps += 1
 
 
-def _wait(pending: List) -> None:
+def _wait(pending: List, probe: Optional[ExchangeProbe] = None) -> None:
+    e0 = probe.before_wait() if probe is not None else None
     for h in pending:
         if h is not None:
             h.wait()                     # torch.distributed: the current stream waits for the collective's stream
+    if probe is not None:
+        probe.after_wait(e0)
     pending.clear()
 
 
-def torch_all_reduce(dist):
+def torch_all_reduce(dist, probe: Optional[ExchangeProbe] = None):
     """Adapter from torch.distributed (backend nccl = RCCL on ROCm, or gloo in the CPU tests) to dp_train_step's callback."""
     def f(t: torch.Tensor, op: str, stream: Optional[int] = None):
         if dist.get_backend() == "gloo":                      # CPU tests / rehearsal: no AVG, and device tensors go through the host
-            h = t.detach().cpu() if t.is_cuda else t
+            t0 = time.perf_counter()
+            if t.is_cuda:
+                # `.cpu()` orders itself behind torch's CURRENT stream only.  A bucket whose last piece was written on a side lane
+                # (UNPREP_WGRAD on the weight-gradient stream) must be complete before the host reads it, and nothing may still
+                # be writing the range when the reduced values are copied back: drain that lane first.
+                if stream is not None:
+                    torch.cuda.ExternalStream(stream).synchronize()
+                h = t.detach().cpu()
+            else:
+                h = t
             dist.all_reduce(h, op=dist.ReduceOp.SUM)
             if op == "avg":
                 h.div_(dist.get_world_size())
             if t.is_cuda:
                 t.copy_(h)
+            if probe is not None:
+                probe.host_ms += (time.perf_counter() - t0) * 1e3
             return None
         rop = dist.ReduceOp.AVG if op == "avg" else dist.ReduceOp.SUM
         if stream is None:

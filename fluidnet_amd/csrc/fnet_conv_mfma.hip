@@ -860,14 +860,14 @@ int fnet_wgrad_mfma(const FnetOp& op, hipStream_t st) {
     // one block per CU over the whole launch: the launch shares the chip with lane 0 (r2 sweep: 256 -> 38.10 ms, 512 -> 38.4 ms per K4 step)
     static const int target_blocks = [] { const char* e = getenv("FNET_WG_BLOCKS"); return e ? atoi(e) : 256; }();
     // 128-pixel chunks (20 % fewer staged bytes per pixel) where every block still gets >= 3 of them; FNET_WG_PX=64|128 forces one size
-    // (read at every launch, so that one test process can run both)
+    // (a knob, so that one test process can run both)
     int px = 64;
     {
         const long long nch128 = (long long)B * ((W + 15) / 16) * ((H + 7) / 8);          // 8 x 16 chunks, see below
         const int want = (target_blocks + tiles - 1) / tiles;
         if (nch128 >= 3ll * want) px = 128;
-        const char* e = getenv("FNET_WG_PX");
-        if (e) px = atoi(e) == 128 ? 128 : 64;
+        const int forced_px = fnet_knob(FNET_KNOB_WG_PX);
+        if (forced_px) px = forced_px == 128 ? 128 : 64;
         // 128-pixel chunks are 8 rows x 16 columns at any image width: 180 source pixels per panel (1.41x) against 204 (1.59x) for 4 x 32
         // -- a pixel's 32 channels are one 64-B DMA segment whatever the chunk shape
         if (px == 128) { log2cw = 4; CW = 16; }

@@ -1395,9 +1395,9 @@ static long long sa_max_pixels() {       // padded pixels per image up to which 
     return v;
 }
 static bool sa_enough_items(int B, int C) {
-    const char* e = getenv("FNET_SA_MINITEMS");               // (read per call: the kernel tests, which use small batches, set it to 1)
-    // (96: K2 256^2 B = 32 gains with 128 blocks, 823 against 802 samples/s; a batch-1 frame -- 4 to 16 blocks -- loses)
-    const long long need = e ? atoll(e) : 96, items = (long long)B * (C / 16);
+    // (96: K2 256^2 B = 32 gains with 128 blocks, 823 against 802 samples/s; a batch-1 frame -- 4 to 16 blocks -- loses; the kernel
+    // tests, which use small batches, set the knob to 1)
+    const long long need = fnet_knob(FNET_KNOB_SA_MINITEMS), items = (long long)B * (C / 16);
     return items >= need && items < (1ll << 30);
 }
 bool fnet_can_fuse_stats_apply(const FnetOp& so, const FnetOp& ao) {
@@ -1419,8 +1419,7 @@ bool fnet_can_fuse_stats_apply(const FnetOp& so, const FnetOp& ao) {
 int fnet_op_stats_apply(const FnetOp& so, const FnetOp& op, hipStream_t st) {
     FNET_CHECK_ARG(fnet_can_fuse_stats_apply(so, op));
     const int B = op.i[0], H = op.i[1], W = op.i[2], C = op.i[3];
-    const char* ecs = getenv("FNET_SA_CS");                  // 16 | 32 forces the slice width (read per launch: the tests run both)
-    const int forced_cs = ecs ? atoi(ecs) : 0;
+    const int forced_cs = fnet_knob(FNET_KNOB_SA_CS);       // 16 | 32 | 64 forces the slice width (the tests run all of them)
     // the widest slice (whole 128-B / 64-B pixel segments) that still gives every CU a block
     int cs = (C % 64 == 0 && (long long)B * (C / 64) >= 256) ? 64 : (C % 32 == 0 && (long long)B * (C / 32) >= 256) ? 32 : 16;
     if (forced_cs == 16 || (forced_cs == 32 && C % 32 == 0) || (forced_cs == 64 && C % 64 == 0)) cs = forced_cs;
@@ -1564,8 +1563,7 @@ bool fnet_can_fuse_inact_bwd(const FnetOp& ro, const FnetOp& ao) {
     if ((ro.i[12] != 0) != (ao.i[13] != 0) || (ao.i[13] != 0 && ao.i[13] != 1)) return false;
     // (<= 32^2 only: at 64^2 the fused launch measured the same as the two -- 52.6 against 51.6 us, 86.6 against 82.8 -- these passes are
     // bound by their arithmetic there, not by launch costs; FNET_SB_MAXHW = the image side, tuning knob)
-    const char* esb = getenv("FNET_SB_MAXHW");              // (read per call: the kernel tests raise it to cover 64^2)
-    const long long sbv = esb ? atoll(esb) : 32, sb_max = (sbv + 2) * (sbv + 2);
+    const long long sbv = fnet_knob(FNET_KNOB_SB_MAXHW), sb_max = (sbv + 2) * (sbv + 2);      // (the kernel tests raise it to cover 64^2)
     if (B <= 0 || H < 2 || W < 2 || C % 16 != 0 || (long long)(H + 2) * (W + 2) > sb_max) return false;
     if (!vec_ok((void*)ao.p[0], ao.i[4], ao.i[5], C, ao.dtype) || !vec_ok((void*)ao.p[1], ao.i[6], ao.i[7], C, ao.dtype) ||
         !vec_ok((void*)ao.p[6], ao.i[8], ao.i[9], C, ao.dtype))
@@ -1576,8 +1574,7 @@ bool fnet_can_fuse_inact_bwd(const FnetOp& ro, const FnetOp& ao) {
 int fnet_op_inact_bwd_fused(const FnetOp& ro, const FnetOp& op, hipStream_t st) {
     FNET_CHECK_ARG(fnet_can_fuse_inact_bwd(ro, op));
     const int B = op.i[0], H = op.i[1], W = op.i[2], C = op.i[3];
-    const char* ecs = getenv("FNET_SA_CS");
-    const int forced_cs = ecs ? atoi(ecs) : 0;
+    const int forced_cs = fnet_knob(FNET_KNOB_SA_CS);
     int cs = (C % 64 == 0 && (long long)B * (C / 64) >= 256) ? 64 : (C % 32 == 0 && (long long)B * (C / 32) >= 256) ? 32 : 16;
     if (forced_cs == 16 || (forced_cs == 32 && C % 32 == 0) || (forced_cs == 64 && C % 64 == 0)) cs = forced_cs;
     const int items = B * (C / cs);

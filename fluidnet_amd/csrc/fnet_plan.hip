@@ -1,6 +1,9 @@
 // Plan executor, hipGraph capture/replay, HIP-event timers: the native runtime under the Python host mirror.
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
+
+#include <mutex>
 
 #include "fnet_common.h"
 
@@ -52,8 +55,12 @@ static int dispatch_op(const FnetOp& op, hipStream_t st) {
 // An op's lane is op.i[FNET_LANE_SLOT]; EVENT_RECORD / EVENT_WAIT order lanes against each other (hipEventRecord on the op's lane,
 // hipStreamWaitEvent of the op's lane on that event).  The plan builder is responsible for joining every side lane back into
 // lane 0 before the plan ends (and before anything reuses a buffer a side lane still reads).  Streams and events are created
-// lazily, once per device and process, and never destroyed (a few hundred bytes each).
+// lazily, once per device and process, and never destroyed (a few hundred bytes each).  The pools are guarded by one mutex, so two host
+// threads may call fnet_plan_run concurrently without corrupting them -- but event ids are per device, not per plan: two plans WITH LANES
+// running at the same time on one device share the events of equal id and may wait on each other's records.  Run plans that use lanes
+// from one thread per device (plans without lanes, e.g. the rollout frame, are independent).
 #define FNET_MAX_DEVICES 16
+static std::mutex g_pool_mu;
 static hipStream_t g_lane_stream[FNET_MAX_DEVICES][FNET_MAX_LANES];
 static hipEvent_t* g_events[FNET_MAX_DEVICES];
 static int g_n_events[FNET_MAX_DEVICES];
@@ -64,6 +71,7 @@ static int lane_stream(int lane, hipStream_t caller, hipStream_t* out) {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess || dev < 0 || dev >= FNET_MAX_DEVICES) { g_fnet_last_hip_error = (int)e; return FNET_E_HIP; }
+    std::lock_guard<std::mutex> lk(g_pool_mu);
     if (!g_lane_stream[dev][lane]) {
         e = hipStreamCreateWithFlags(&g_lane_stream[dev][lane], hipStreamNonBlocking);
         if (e != hipSuccess) { g_fnet_last_hip_error = (int)e; return FNET_E_HIP; }
@@ -77,11 +85,12 @@ static int plan_event(int id, hipEvent_t* out) {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess || dev < 0 || dev >= FNET_MAX_DEVICES) { g_fnet_last_hip_error = (int)e; return FNET_E_HIP; }
+    std::lock_guard<std::mutex> lk(g_pool_mu);
     if (id >= g_n_events[dev]) {
         int n = g_n_events[dev] ? g_n_events[dev] : 256;
         while (n <= id) n *= 2;
         hipEvent_t* p = (hipEvent_t*)realloc(g_events[dev], sizeof(hipEvent_t) * n);
-        if (!p) return FNET_E_HIP;
+        if (!p) { g_fnet_last_hip_error = (int)hipErrorOutOfMemory; return FNET_E_HIP; }
         for (int k = g_n_events[dev]; k < n; ++k) p[k] = nullptr;
         g_events[dev] = p;
         g_n_events[dev] = n;
@@ -92,6 +101,24 @@ static int plan_event(int id, hipEvent_t* out) {
     }
     *out = g_events[dev][id];
     return FNET_OK;
+}
+
+// ---- tuning knobs (fnet_common.h): name, environment variable, default
+static const struct { const char* name; const char* env; int dflt; } g_knob_def[FNET_KNOB_COUNT] = {
+    {"sa_minitems", "FNET_SA_MINITEMS", 96},   // fewest (image, 16-channel slice) blocks for which a norm / activation pair is fused
+    {"sa_cs", "FNET_SA_CS", 0},                // forced channel-slice width of the fused launches (0: widest with a block per CU)
+    {"sb_maxhw", "FNET_SB_MAXHW", 32},         // largest image side whose adjoint pair is fused
+    {"wg_px", "FNET_WG_PX", 0},                // forced weight-gradient chunk size, 64 | 128 (0: by chunk count)
+};
+static int g_knob[FNET_KNOB_COUNT];
+static std::once_flag g_knob_once;
+static int knob_from_env(int id) {
+    const char* e = getenv(g_knob_def[id].env);
+    return e ? atoi(e) : g_knob_def[id].dflt;
+}
+int fnet_knob(int id) {
+    std::call_once(g_knob_once, [] { for (int k = 0; k < FNET_KNOB_COUNT; ++k) g_knob[k] = knob_from_env(k); });
+    return (id >= 0 && id < FNET_KNOB_COUNT) ? g_knob[id] : 0;
 }
 
 struct FnetGraph {
@@ -183,6 +210,18 @@ int fnet_plan_run(const FnetOp* ops, int32_t n_ops, void* stream, int32_t* faile
     }
     if (failed_index) *failed_index = -1;
     return FNET_OK;
+}
+
+int fnet_set_knob(const char* name, int32_t value) {
+    if (!name) return FNET_E_BADARG;
+    fnet_knob(0);                                        // make sure the environment was read first
+    for (int k = 0; k < FNET_KNOB_COUNT; ++k)
+        if (!strcmp(name, g_knob_def[k].name)) {
+            std::lock_guard<std::mutex> lk(g_pool_mu);
+            g_knob[k] = value < 0 ? knob_from_env(k) : value;
+            return FNET_OK;
+        }
+    return FNET_E_BADARG;
 }
 
 int fnet_lane_stream(int32_t lane, void** stream_out) {

@@ -28,6 +28,7 @@ OPC = dict(NOP=0, PACK_INPUT=1, CONV3X3=2, WGRAD=3, IN_STATS=4, APPLY=5, UPSAMPL
            UNPACK_GRAD=21, ZERO=22, PREP_WEIGHTS=23, GRAD_NORM=24, ADAM=25, COPY_PLANES=26, UNPREP_WGRAD=27, STENCIL=28,
            AFFINE_GRAD_MULTI=29, METRICS=30, GATHER_BATCH=31, POOL2X=32, POOL2X_BWD=33, NORM_COMBINE=34, NORM_COMBINE_BWD=35, DEPTH2SPACE=36, SPACE2DEPTH=37,
            EVENT_RECORD=38, EVENT_WAIT=39)
+ABI_VERSION = 2       # include/fluidnet_hip.h FNET_ABI_VERSION: the FnetOp slot meanings this module writes
 LANE_SLOT = 29        # FnetOp.i[29]: the lane (stream) an op runs on; include/fluidnet_hip.h FNET_LANE_SLOT
 OPNAME = {v: k for k, v in OPC.items()}
 
@@ -93,13 +94,16 @@ def lib() -> ctypes.CDLL:
     for name, args in sigs.items():
         getattr(L, name).restype = ctypes.c_int
         getattr(L, name).argtypes = args
-    if L.fnet_abi_version() != 1:
-        raise FluidNetHipError("libfluidnet_hip.so ABI version mismatch; rebuild with `python -m fluidnet_amd.build --force`")
+    L.fnet_set_knob.restype = ctypes.c_int
+    L.fnet_set_knob.argtypes = [ctypes.c_char_p, ctypes.c_int32]
+    if L.fnet_abi_version() != ABI_VERSION:
+        raise FluidNetHipError(f"{LIB_PATH} has ABI version {L.fnet_abi_version()}, this package needs {ABI_VERSION} (FnetOp slot meanings "
+                               "differ): rebuild with `python -m fluidnet_amd.build --force`")
     _lib = L
     return L
 
 
-EXPORTS = ["fnet_abi_version", "fnet_strerror", "fnet_last_hip_error", "fnet_device_info", "fnet_plan_run", "fnet_lane_stream", "fnet_physics_loss_terms_noalloc", "fnet_graph_create",
+EXPORTS = ["fnet_abi_version", "fnet_strerror", "fnet_last_hip_error", "fnet_device_info", "fnet_plan_run", "fnet_lane_stream", "fnet_set_knob", "fnet_physics_loss_terms_noalloc", "fnet_graph_create",
            "fnet_graph_launch", "fnet_graph_destroy", "fnet_spatial_gradients", "fnet_divergence", "fnet_timer_create",
            "fnet_timer_start", "fnet_timer_stop", "fnet_timer_elapsed_ms", "fnet_timer_destroy", "fnet_unet_param_count",
            "fnet_rollout_create", "fnet_rollout_set_weights", "fnet_rollout_set_masks", "fnet_rollout_set_state", "fnet_rollout_add_impulse",
@@ -132,6 +136,11 @@ def run_ops(ops: np.ndarray, stream: Optional[int] = None) -> None:
     failed = ctypes.c_int32(-1)
     rc = lib().fnet_plan_run(ops.ctypes.data_as(ctypes.c_void_p), len(ops), ctypes.c_void_p(st), ctypes.byref(failed))
     check(rc, "fnet_plan_run", ops, failed.value)
+
+
+def set_knob(name: str, value: int) -> None:
+    """fnet_set_knob: override a launch heuristic (tests / A-B runs); value < 0 restores the environment's value or the default."""
+    check(lib().fnet_set_knob(name.encode(), int(value)), f"fnet_set_knob({name})")
 
 
 def lane_stream(lane: int) -> int:

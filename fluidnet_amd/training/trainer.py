@@ -113,6 +113,7 @@ class Trainer:
         except Exception:
             self._dist = None
         self._rank = self._dist.get_rank() if self._dist is not None else 0
+        self._shard_checked = False
         self._world = self._dist.get_world_size() if self._dist is not None else 1
         if self._dist is not None and engine != "plan":
             # the autograd engine has no gradient exchange: ranks would silently train different models
@@ -214,6 +215,16 @@ class Trainer:
         if n % self._world:
             raise RuntimeError(f"data-parallel training: a global batch of {n} samples cannot be split over {self._world} ranks "
                                "(use drop_last=True and a batch size divisible by the world size)")
+        if not self._shard_checked:
+            # nothing makes two ranks' plain DataLoaders draw the same permutation (shuffle=True uses each process's own RNG): check
+            # once that every rank holds the same global batch before slicing it, instead of training on duplicated / missing rows
+            self._shard_checked = True
+            mine = [float(t.double().sum()) for t in batch] + [float(n)]
+            alls = [None] * self._world
+            self._dist.all_gather_object(alls, mine)
+            if any(a != alls[0] for a in alls):
+                raise RuntimeError("data-parallel training with a plain DataLoader: the ranks drew different global batches (seed the "
+                                   "loader's generator identically on every rank, or use DistributedSampler / HbmBatchLoader(rank=, world=))")
         b = n // self._world
         return tuple(t[self._rank * b:(self._rank + 1) * b] for t in batch)
 
@@ -310,13 +321,17 @@ class Trainer:
             if self.scheduler is not None:
                 self.scheduler.step(va["total"])
             if self.early_stopping is not None:
+                # data parallel: every rank validates the same weights on the same split, so the decisions agree; rank 0 alone writes
                 if self.early_stopping(va["total"], epoch):
-                    self.early_stopping.save_checkpoint(self.model, self.optimizer, None, self.config, epoch)
+                    if self._rank == 0:
+                        self.early_stopping.save_checkpoint(self.model, self.optimizer, None, self.config, epoch)
                     break
-                if self.early_stopping.counter == 0:
+                if self.early_stopping.counter == 0 and self._rank == 0:
                     self.early_stopping.save_checkpoint(self.model, self.optimizer, None, self.config, epoch)
             if (epoch + 1) % self.config.save_every_n_epochs == 0:
                 self.save_checkpoint(epoch)
+        if self._dist is not None:
+            self._dist.barrier()                 # rank 0's best_model.pth is complete before any rank reads it back
         if self.early_stopping is not None:
             self.early_stopping.load_best_checkpoint(self.model, self.optimizer, None, self.device)
         else:
@@ -324,6 +339,8 @@ class Trainer:
 
     # ------------------------------------------------------------------ checkpoints (trainer.py:717-784)
     def save_checkpoint(self, epoch: int, final: bool = False) -> None:
+        if self._rank != 0:                      # replicas hold identical state: one writer per checkpoint directory
+            return
         ck: Dict[str, Any] = {"epoch": epoch, "model_state_dict": {k: v.detach().cpu() for k, v in self.model.state_dict().items()},
                               "optimizer_state_dict": self.optimizer.state_dict(), "config": self.config.model_dump(mode="json")}
         if self.scheduler is not None:

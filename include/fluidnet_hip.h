@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define FNET_ABI_VERSION 1
+#define FNET_ABI_VERSION 2        /* 2: FnetOp slot meanings of round 2 (CONV3X3 mode, lanes in slot 29), fnet_set_knob */
 
 /* error codes */
 #define FNET_OK 0
@@ -158,6 +158,11 @@ int fnet_plan_run(const FnetOp* ops, int32_t n_ops, void* stream, int32_t* faile
  * library.  No reference counterpart (the reference is single-stream): the data-parallel host uses it to order a gradient
  * bucket's RCCL all-reduce behind the lane that produced the bucket's last piece (fluidnet_amd/training/dp.py). */
 int fnet_lane_stream(int32_t lane, void** stream_out);
+/* Development / test control with no reference counterpart: overrides one of the launch heuristics that the library otherwise reads
+ * from the environment once per process ("sa_minitems", "sa_cs", "sb_maxhw", "wg_px" = FNET_SA_MINITEMS, FNET_SA_CS, FNET_SB_MAXHW,
+ * FNET_WG_PX; INTEGRATION.md "Development knobs").  value < 0 restores the environment's value or the default.  FNET_E_BADARG for an
+ * unknown name.  Results never depend on a knob beyond summation order; production code does not call this. */
+int fnet_set_knob(const char* name, int32_t value);
 
 /*
  * hipGraph form of fnet_plan_run for launch-bound loops (the 600-frame rollout of

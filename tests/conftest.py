@@ -35,3 +35,17 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture
+def knobs():
+    """Set launch-heuristic knobs of the library for one test (fnet_set_knob; restored to the environment's value / default after)."""
+    from fluidnet_amd.engine import runtime as rt
+    used = []
+
+    def set_(name, value):
+        rt.set_knob(name, int(value))
+        used.append(name)
+    yield set_
+    for name in used:
+        rt.set_knob(name, -1)

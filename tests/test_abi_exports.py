@@ -26,7 +26,7 @@ def test_every_declared_function_is_exported():
     missing = [d for d in decls if not hasattr(L, d)]
     assert not missing, missing
     assert sorted(decls) == sorted(rt.EXPORTS)
-    assert L.fnet_abi_version() == 1
+    assert L.fnet_abi_version() == rt.ABI_VERSION == 2
     assert L.fnet_strerror(-1).decode() and L.fnet_strerror(-2).decode()
 
 
@@ -82,3 +82,12 @@ def test_native_param_count_matches_the_state_dict(tmp_path):
     out = subprocess.check_output([str(exe)]).split()
     assert int(out[0]) == 0 and int(out[1]) == want
     assert int(out[2]) == -1                       # FNET_E_BADARG for an unsupported configuration
+
+
+def test_knob_setter_is_host_only_and_rejects_unknown_names():
+    """fnet_set_knob (no getenv on the launch path; tests override the cached values through an exported setter)."""
+    from fluidnet_amd.engine import runtime as rt
+    rt.set_knob("wg_px", 128)
+    rt.set_knob("wg_px", -1)                 # back to the environment's value / default
+    with pytest.raises(rt.FluidNetHipError):
+        rt.set_knob("no_such_knob", 1)

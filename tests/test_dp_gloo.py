@@ -164,6 +164,16 @@ def _trainer_worker(rank, world, port, outdir):
         sharded = True
     tr2 = Trainer(model, _Sharded([batch]), [], cfg, "cpu", engine="plan", max_plans=0)
     res["presharded_untouched"] = tr2._shard(batch)[0].shape[0] == B
+    # ranks whose plain loaders drew different global batches must be told so, not sliced
+    tr3 = Trainer(model, [batch], [], cfg, "cpu", engine="plan", max_plans=0)
+    other = tuple(t + float(rank) for t in batch)
+    try:
+        tr3._shard(other)
+        res["mismatch_refused"] = False
+    except RuntimeError as e:
+        res["mismatch_refused"] = "different global batches" in str(e)
+    tr.save_checkpoint(0)
+    res["wrote_checkpoint"] = os.path.exists(os.path.join(str(tr.config.checkpoint_dir), "checkpoint_epoch_1.pth"))
     res["seed"] = step_seed(5, rank)
     torch.save(res, os.path.join(outdir, f"tr{rank}.pt"))
     dist.destroy_process_group()
@@ -181,3 +191,5 @@ def test_trainer_under_data_parallel_shards_and_refuses_unsynchronised_paths():
         assert r[k]["shapes"][0] == (B // 2, 6, R, R)
         assert np.allclose(r[k]["rows"], x0[k * (B // 2):(k + 1) * (B // 2), 0, 0, 0])
     assert r[0]["seed"] != r[1]["seed"]
+    assert r[0]["mismatch_refused"] is True and r[1]["mismatch_refused"] is True
+    assert r[0]["wrote_checkpoint"] and not r[1]["wrote_checkpoint"]          # one writer: rank 0

@@ -103,19 +103,19 @@ WG_PIPE_SHAPES = [
 
 @pytest.mark.parametrize("px", ["64", "128"])
 @pytest.mark.parametrize("shape", WG_PIPE_SHAPES, ids=[f"B{s[0]}_{s[1]}x{s[2]}_{s[3]}to{s[4]}" for s in WG_PIPE_SHAPES])
-def test_wgrad_multi_chunk_pipeline(shape, px, monkeypatch):
-    # both chunk sizes of k_wgrad_dma (64 and 128 pixels; the launcher reads FNET_WG_PX at every launch)
-    monkeypatch.setenv("FNET_WG_PX", px)
+def test_wgrad_multi_chunk_pipeline(shape, px, knobs):
+    # both chunk sizes of k_wgrad_dma (64 and 128 pixels), forced through the wg_px knob
+    knobs("wg_px", px)
     pb, ops = _mk(*shape, "bf16", "mfma")
     failures = lockstep(pb, ops[1:])
     assert not failures, "\n".join(failures)
 
 
 @pytest.mark.parametrize("px", ["64", "128"])
-def test_wgrad_chunk_sizes_on_every_shape(px, monkeypatch):
+def test_wgrad_chunk_sizes_on_every_shape(px, knobs):
     """The weight gradient of every shape above (ragged images, channel slices, W <= 16 and W > 16 chunk shapes, the 2x2 stride-2 form)
     with the chunk size forced, whatever the launcher would pick by itself."""
-    monkeypatch.setenv("FNET_WG_PX", px)
+    knobs("wg_px", px)
     for shape in SHAPES:
         pb, ops = _mk(*shape, "bf16", "mfma")
         failures = lockstep(pb, ops[1:])

@@ -15,9 +15,9 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(autouse=True)
-def _fuse_small_batches(monkeypatch):
+def _fuse_small_batches(knobs):
     # the library fuses only where B * C / 16 >= 96 (enough blocks); these kernel tests use small batches
-    monkeypatch.setenv("FNET_SA_MINITEMS", "1")
+    knobs("sa_minitems", 1)
 
 
 ACTS = {"relu": 0, "leaky": 1, "gelu": 2, "silu": 3}
@@ -72,8 +72,8 @@ def _run(arr, st, dst, together):
 
 @pytest.mark.parametrize("cs", ["16", "32", "64"])
 @pytest.mark.parametrize("case", CASES, ids=[f"B{c[0]}_{c[1]}x{c[2]}_C{c[3]}_{c[7]}_pm{c[8]}" for c in CASES])
-def test_fused_stats_apply_equals_separate_launches(case, cs, monkeypatch):
-    monkeypatch.setenv("FNET_SA_CS", cs)       # every slice width of the kernel (64 falls back where C % 64 != 0) (the launcher picks by block count otherwise)
+def test_fused_stats_apply_equals_separate_launches(case, cs, knobs):
+    knobs("sa_cs", cs)       # every slice width of the kernel (64 falls back where C % 64 != 0) (the launcher picks by block count otherwise)
     pb, ops, st, dst = _mk(*case)
     arr = lower(pb, ops)
     s1, d1 = _run(arr, st, dst, together=False)
@@ -93,9 +93,9 @@ def test_fused_stats_apply_equals_separate_launches(case, cs, monkeypatch):
     assert torch.equal(s2, s3) and torch.equal(d2, d3)
 
 
-def test_small_batches_do_not_fuse(monkeypatch):
+def test_small_batches_do_not_fuse(knobs):
     # B * C / 16 = 2 * 4 < 96: the pair runs as its separate launches inside one call too -> bit-identical to one call per record
-    monkeypatch.delenv("FNET_SA_MINITEMS")
+    knobs("sa_minitems", 96)
     pb, ops, st, dst = _mk(2, 32, 32, 64, 64, 0, False, "gelu", 1, 0.0)
     arr = lower(pb, ops)
     s1, d1 = _run(arr, st, dst, together=False)
@@ -185,11 +185,11 @@ def _run_bwd(arr, S, draw, together):
 
 @pytest.mark.parametrize("cs", ["16", "32", "64"])
 @pytest.mark.parametrize("case", BWD_CASES, ids=[f"B{c[0]}_{c[1]}x{c[2]}_C{c[3]}_{c[7]}_pm{c[8]}_fold{c[6]}" for c in BWD_CASES])
-def test_fused_adjoint_equals_separate_launches(case, cs, monkeypatch):
-    # (the library fuses the adjoint pair up to 32^2 by default -- at 64^2 it measured the same as the two launches; FNET_SB_MAXHW, read
-    # at every call, raises the limit so that the 64^2 cases above exercise the kernel too)
-    monkeypatch.setenv("FNET_SA_CS", cs)
-    monkeypatch.setenv("FNET_SB_MAXHW", "64")
+def test_fused_adjoint_equals_separate_launches(case, cs, knobs):
+    # (the library fuses the adjoint pair up to 32^2 by default -- at 64^2 it measured the same as the two launches; the sb_maxhw knob
+    # raises the limit so that the 64^2 cases above exercise the kernel too)
+    knobs("sa_cs", cs)
+    knobs("sb_maxhw", 64)
     pb, ops, S, draw = _mk_bwd(*case)
     arr = lower(pb, ops)
     s1, d1 = _run_bwd(arr, S, draw, together=False)

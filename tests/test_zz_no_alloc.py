@@ -1,17 +1,22 @@
 """fnet_physics_loss_terms_noalloc (include/fluidnet_hip.h): the allocation-free variant of the ZERO + LOSS_REDUCE + LOSS_FINALIZE op
 sequence of fnet_plan_run, whose fp64 sums live in a static __device__ array of the library.  Called through the C ABI (ctypes) and
 compared with fnet_plan_run on the same inputs -- two calls in a row, the second with a smaller input (the array keeps the first
-call's sums unless the entry point clears them).  Tolerance: the sums are fp64 atomics in both paths, the terms fp32: 1e-6 relative."""
+call's sums unless the entry point clears them).  Tolerance: the sums are fp64 atomics in both paths, the terms fp32: 1e-6 relative.
+Both shapes are also checked against the CPU oracle's physics_loss (PhysicsAwareLoss.forward, ml/training/physics_loss.py:210-278) on the
+same inputs: fp32 torch reductions against fp64 device sums, 2e-5 relative."""
 import ctypes
 
 import numpy as np
 import pytest
 import torch
 
+import fluidnet_oracle as orc
 from fluidnet_amd.engine import runtime as rt
 
 pytestmark = pytest.mark.gpu
 W_ = (1.0, 0.01, 0.001, 0.01)
+PAD_NAME = {v: k for k, v in rt.PAD.items()}
+STENCIL_NAME = {v: k for k, v in rt.STENCIL.items()}
 
 
 def _inputs(B, H, W, seed):
@@ -66,6 +71,11 @@ def test_noalloc_matches_plan_run_twice_second_smaller():
         got = terms.cpu().numpy()
         assert np.all(np.isfinite(got[:6])) and want[5] > 0
         np.testing.assert_allclose(got[:6], want[:6], rtol=1e-6, atol=1e-9)
+        # the oracle on the same inputs: terms[0..4] = mse, divergence, gradient, emitter, total (disabled terms are absent / 0)
+        lc = orc.LossConfig(*W_, 2.0 / W, bool(flags & 1), bool(flags & 2), bool(flags & 4), PAD_NAME[pm], STENCIL_NAME[stencil])
+        total, d = orc.physics_loss(pred.cpu(), tgt.cpu(), x.cpu(), lc)
+        ref = [float(d.get(k, 0.0)) for k in ("mse", "divergence", "gradient", "emitter")] + [float(total)]
+        np.testing.assert_allclose(got[:5], ref, rtol=2e-5, atol=1e-7)
 
 
 def test_noalloc_rejects_oversize_and_bad_arguments():

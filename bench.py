@@ -157,10 +157,9 @@ class TrainStepper:
     def next_batch(self):
         if not self._batches:
             self.loader.set_epoch(self._epoch)
-            self._batches = list(self.loader.batches())
+            self._batches = list(range(self.loader.upload_epoch()))          # one index / flip-flag upload per epoch
             self._epoch += 1
-        rows, flips = self._batches.pop()
-        self.loader.gather(rows, flips, self.plan.x0.tensor, self.plan.y.tensor, self.plan.masks.tensor)
+        self.loader.gather_uploaded(self._batches.pop(), self.plan.x0.tensor, self.plan.y.tensor, self.plan.masks.tensor)
 
     def step(self):
         self.t += 1

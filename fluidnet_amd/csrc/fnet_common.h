@@ -315,6 +315,7 @@ int fnet_op_stats_apply(const FnetOp& stats_op, const FnetOp& apply_op, hipStrea
 bool fnet_can_fuse_inact_bwd(const FnetOp& reduce_op, const FnetOp& apply_op);                             // INACT_BWD_REDUCE + INACT_BWD_APPLY, single source, small image
 int fnet_op_inact_bwd_fused(const FnetOp& reduce_op, const FnetOp& apply_op, hipStream_t st);
 int fnet_op_prep_weights_batch(const FnetOp* ops, int n, hipStream_t st, int* n_done);   // consecutive PREP_WEIGHTS records, one launch per 32
+int fnet_op_unprep_wgrad_batch(const FnetOp* ops, int n, hipStream_t st, int* n_done);  // consecutive UNPREP_WGRAD records, one launch per 32
 FNET_DECL_OP(fnet_op_grad_norm);
 FNET_DECL_OP(fnet_op_adam);
 FNET_DECL_OP(fnet_op_copy_planes);

@@ -60,12 +60,14 @@ __global__ __launch_bounds__(256) void k_prep_weights_t2(const float* W, T* Wf, 
     prep_elem_t2<T>(blockIdx.x * kThreads + threadIdx.x, W, Wf, Wd, Cout, Cin, Kf, Cout_d, blocked, Kd);
 }
 // dW[ci][co][a][b] (+)= dWk[4][q*Cout + co][ci]
-__global__ __launch_bounds__(256) void k_unprep_wgrad_t2(const float* dWk, float* dW, int Cout, int Cin, int Cin_w, int accumulate) {
-    const int idx = blockIdx.x * kThreads + threadIdx.x;
+__device__ __forceinline__ void unprep_elem_t2(int idx, const float* dWk, float* dW, int Cout, int Cin, int Cin_w, int accumulate) {
     if (idx >= Cin * Cout * 4) return;
     const int q = idx & 3, co = (idx >> 2) % Cout, ci = idx / (4 * Cout);
     const float v = dWk[((size_t)4 * (4 * Cout) + q * Cout + co) * Cin_w + ci];
     dW[idx] = accumulate ? dW[idx] + v : v;
+}
+__global__ __launch_bounds__(256) void k_unprep_wgrad_t2(const float* dWk, float* dW, int Cout, int Cin, int Cin_w, int accumulate) {
+    unprep_elem_t2(blockIdx.x * kThreads + threadIdx.x, dWk, dW, Cout, Cin, Cin_w, accumulate);
 }
 
 // Conv2d(C, Cout, 3, stride 2, padding 1) as the 2x2-tap convolution over the space-to-depth view of its input (k_conv3x3_dma, MODE 1 / 2):
@@ -128,8 +130,7 @@ __global__ __launch_bounds__(256) void k_prep_weights_multi(PrepBatch pb) {
     else prep_elem<T>(idx, d.W, (T*)d.Wf, (T*)d.Wd, d.Cout, d.Cin, d.a2, d.Cout_d, d.blocked, d.Cout_pad, d.Kd);
 }
 // dW[co][c][ky][kx] (+)= dWk[(ky>>1, kx>>1)][co][((ky&1), (kx&1), c)]
-__global__ __launch_bounds__(256) void k_unprep_wgrad_s2(const float* dWk, float* dW, int Cout, int C, int Cin_w, int accumulate, int Cout_pad) {
-    const int idx = blockIdx.x * kThreads + threadIdx.x;
+__device__ __forceinline__ void unprep_elem_s2(int idx, const float* dWk, float* dW, int Cout, int C, int Cin_w, int accumulate, int Cout_pad) {
     if (idx >= Cout * C * 9) return;
     const int tt = idx % 9, c = (idx / 9) % C, co = idx / (9 * C);
     const int ky = tt / 3, kx = tt - ky * 3;
@@ -137,14 +138,41 @@ __global__ __launch_bounds__(256) void k_unprep_wgrad_s2(const float* dWk, float
     const float v = dWk[((size_t)t * Cout_pad + co) * Cin_w + ph * C + c];
     dW[idx] = accumulate ? dW[idx] + v : v;
 }
+__global__ __launch_bounds__(256) void k_unprep_wgrad_s2(const float* dWk, float* dW, int Cout, int C, int Cin_w, int accumulate, int Cout_pad) {
+    unprep_elem_s2(blockIdx.x * kThreads + threadIdx.x, dWk, dW, Cout, C, Cin_w, accumulate, Cout_pad);
+}
 
 // dW[co][ci][t] (+)= dWk[t][co][ci]   (dWk rows = Cout_pad, row pitch Cin_w; padded rows / columns are dropped)
-__global__ __launch_bounds__(256) void k_unprep_wgrad(const float* dWk, float* dW, int Cout, int Cin, int Cin_w, int accumulate, int Cout_pad) {
-    const int idx = blockIdx.x * kThreads + threadIdx.x;
+__device__ __forceinline__ void unprep_elem(int idx, const float* dWk, float* dW, int Cout, int Cin, int Cin_w, int accumulate, int Cout_pad) {
     if (idx >= Cout * Cin * 9) return;
     const int t = idx % 9, ci = (idx / 9) % Cin, co = idx / (9 * Cin);
     const float v = dWk[((size_t)t * Cout_pad + co) * Cin_w + ci];
     dW[idx] = accumulate ? dW[idx] + v : v;
+}
+__global__ __launch_bounds__(256) void k_unprep_wgrad(const float* dWk, float* dW, int Cout, int Cin, int Cin_w, int accumulate, int Cout_pad) {
+    unprep_elem(blockIdx.x * kThreads + threadIdx.x, dWk, dW, Cout, Cin, Cin_w, accumulate, Cout_pad);
+}
+
+// Several UNPREP_WGRAD records in one launch (as k_prep_weights_multi: the ~30 folds at the end of a backward pass were 3-4 us kernels
+// with 15-75 us of idle queue between them in the kernel trace); the same element code as the single-record kernels.
+struct UnprepDesc {
+    const float* dWk;
+    float* dW;
+    int Cout, Cin, Cin_w, accumulate, Cout_pad, kind;
+};
+struct UnprepBatch {
+    UnprepDesc d[PREP_MAXB];
+    int blk0[PREP_MAXB + 1];
+    int n;
+};
+__global__ __launch_bounds__(256) void k_unprep_wgrad_multi(UnprepBatch ub) {
+    int j = 0;
+    while (j + 1 < ub.n && (int)blockIdx.x >= ub.blk0[j + 1]) ++j;      // wave-uniform scan over <= 32 entries
+    const UnprepDesc& d = ub.d[j];
+    const int idx = ((int)blockIdx.x - ub.blk0[j]) * kThreads + threadIdx.x;
+    if (d.kind == 1) unprep_elem_t2(idx, d.dWk, d.dW, d.Cout, d.Cin, d.Cin_w, d.accumulate);
+    else if (d.kind == 2) unprep_elem_s2(idx, d.dWk, d.dW, d.Cout, d.Cin, d.Cin_w, d.accumulate, d.Cout_pad);
+    else unprep_elem(idx, d.dWk, d.dW, d.Cout, d.Cin, d.Cin_w, d.accumulate, d.Cout_pad);
 }
 
 __global__ __launch_bounds__(256) void k_grad_norm(const float* g, double* out, long long n) {
@@ -266,29 +294,52 @@ int fnet_op_prep_weights_batch(const FnetOp* ops, int n, hipStream_t st, int* n_
 
 // UNPREP_WGRAD  i: 0 Cout,1 Cin,2 Cin_w,3 accumulate,4 Cout_pad (0 = Cout),5 kind (0 conv3x3, 1 transposed 2x2, 2 conv3x3 stride 2 in 2x2
 //                  form: dWk [4][Cout_pad][Cin_w >= 4 Cin]); p: 0 dWk fp32 [9][Cout_pad][Cin_w],1 dW fp32 OIHW
-int fnet_op_unprep_wgrad(const FnetOp& op, hipStream_t st) {
+// validates one record and fills its descriptor and element count (what the single-record launch and the batch both use)
+static int unprep_describe(const FnetOp& op, UnprepDesc* d, int* total) {
     const int Cout = op.i[0], Cin = op.i[1], Cin_w = op.i[2], Cout_pad = op.i[4] ? op.i[4] : Cout;
     FNET_CHECK_ARG(Cout > 0 && Cin > 0 && Cin_w >= Cin && Cout_pad >= Cout && op.p[0] && op.p[1]);
-    if (op.i[5] == 1) {                      // transposed 2x2: dWk fp32 [9][4*Cout][Cin_w] -> dW [Cin][Cout][2][2]
-        const int n = Cin * Cout * 4;
-        hipLaunchKernelGGL(k_unprep_wgrad_t2, dim3((n + kThreads - 1) / kThreads), dim3(kThreads), 0, st, (const float*)op.p[0],
-                           (float*)op.p[1], Cout, Cin, Cin_w, op.i[3]);
-        FNET_LAUNCH_CHECK();
-        return FNET_OK;
-    }
-    if (op.i[5] == 2) {
-        FNET_CHECK_ARG(Cin_w >= 4 * Cin);
-        const int n = 9 * Cout * Cin;
-        hipLaunchKernelGGL(k_unprep_wgrad_s2, dim3((n + kThreads - 1) / kThreads), dim3(kThreads), 0, st, (const float*)op.p[0],
-                           (float*)op.p[1], Cout, Cin, Cin_w, op.i[3], Cout_pad);
-        FNET_LAUNCH_CHECK();
-        return FNET_OK;
-    }
-    FNET_CHECK_ARG(op.i[5] == 0);
-    const int total = 9 * Cout * Cin;
-    hipLaunchKernelGGL(k_unprep_wgrad, dim3((total + kThreads - 1) / kThreads), dim3(kThreads), 0, st, (const float*)op.p[0],
-                       (float*)op.p[1], Cout, Cin, Cin_w, op.i[3], Cout_pad);
+    FNET_CHECK_ARG(op.i[5] >= 0 && op.i[5] <= 2 && (op.i[5] != 2 || Cin_w >= 4 * Cin));
+    *d = UnprepDesc{(const float*)op.p[0], (float*)op.p[1], Cout, Cin, Cin_w, op.i[3], Cout_pad, op.i[5]};
+    *total = op.i[5] == 1 ? Cin * Cout * 4 : 9 * Cout * Cin;      // transposed 2x2: dWk fp32 [9][4*Cout][Cin_w] -> dW [Cin][Cout][2][2]
+    return FNET_OK;
+}
+
+int fnet_op_unprep_wgrad(const FnetOp& op, hipStream_t st) {
+    UnprepDesc d;
+    int total = 0;
+    const int rc = unprep_describe(op, &d, &total);
+    if (rc != FNET_OK) return rc;
+    const dim3 grid((total + kThreads - 1) / kThreads);
+    if (d.kind == 1) hipLaunchKernelGGL(k_unprep_wgrad_t2, grid, dim3(kThreads), 0, st, d.dWk, d.dW, d.Cout, d.Cin, d.Cin_w, d.accumulate);
+    else if (d.kind == 2) hipLaunchKernelGGL(k_unprep_wgrad_s2, grid, dim3(kThreads), 0, st, d.dWk, d.dW, d.Cout, d.Cin, d.Cin_w, d.accumulate, d.Cout_pad);
+    else hipLaunchKernelGGL(k_unprep_wgrad, grid, dim3(kThreads), 0, st, d.dWk, d.dW, d.Cout, d.Cin, d.Cin_w, d.accumulate, d.Cout_pad);
     FNET_LAUNCH_CHECK();
+    return FNET_OK;
+}
+
+// n consecutive UNPREP_WGRAD records in ceil(n / 32) launches (same contract as fnet_op_prep_weights_batch)
+int fnet_op_unprep_wgrad_batch(const FnetOp* ops, int n, hipStream_t st, int* n_done) {
+    *n_done = 0;
+    while (*n_done < n) {
+        UnprepBatch ub;
+        ub.n = 0;
+        ub.blk0[0] = 0;
+        int rc = FNET_OK;
+        while (ub.n < PREP_MAXB && *n_done + ub.n < n) {
+            int total = 0;
+            rc = unprep_describe(ops[*n_done + ub.n], &ub.d[ub.n], &total);
+            if (rc != FNET_OK) break;
+            ub.blk0[ub.n + 1] = ub.blk0[ub.n] + (total + kThreads - 1) / kThreads;
+            ++ub.n;
+        }
+        if (ub.n > 0) {
+            for (int j = ub.n + 1; j <= PREP_MAXB; ++j) ub.blk0[j] = ub.blk0[ub.n];
+            hipLaunchKernelGGL(k_unprep_wgrad_multi, dim3(ub.blk0[ub.n]), dim3(kThreads), 0, st, ub);
+            FNET_LAUNCH_CHECK();
+            *n_done += ub.n;
+        }
+        if (rc != FNET_OK) return rc;
+    }
     return FNET_OK;
 }
 

@@ -199,6 +199,13 @@ int fnet_plan_run(const FnetOp* ops, int32_t n_ops, void* stream, int32_t* faile
                 int done = 0;
                 rc = fnet_op_prep_weights_batch(ops + k, m, st, &done);
                 k += rc == FNET_OK ? m - 1 : done;            // on failure k is the offending record
+            } else if (ops[k].op == FNET_OP_UNPREP_WGRAD && k + 1 < n_ops && ops[k + 1].op == FNET_OP_UNPREP_WGRAD && prep_batching) {
+                // ... and so does a run of weight-gradient folds of one lane (the end of a backward pass, a data-parallel bucket)
+                int32_t m = 1;
+                while (k + m < n_ops && ops[k + m].op == FNET_OP_UNPREP_WGRAD && ops[k + m].i[FNET_LANE_SLOT] == ops[k].i[FNET_LANE_SLOT]) ++m;
+                int done = 0;
+                rc = fnet_op_unprep_wgrad_batch(ops + k, m, st, &done);
+                k += rc == FNET_OK ? m - 1 : done;
             } else {
                 rc = dispatch_op(ops[k], st);
             }

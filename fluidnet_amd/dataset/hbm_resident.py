@@ -91,6 +91,7 @@ class HbmBatchLoader:
         self._host = torch.zeros(2, 2, batch_size, dtype=torch.int32).pin_memory() if dev.type == "cuda" else torch.zeros(2, 2, batch_size, dtype=torch.int32)
         self._host_ev = [None, None]
         self._slot = 0
+        self._table = self._table_host = self._table_ev = None      # upload_epoch(): the whole epoch's indices / flags on the device
 
     def set_epoch(self, epoch: int) -> None:
         self.epoch = epoch
@@ -117,10 +118,8 @@ class HbmBatchLoader:
             out.append((rows, flips.astype(np.int32)))
         return out
 
-    def gather(self, rows: np.ndarray, flips: np.ndarray, x0: torch.Tensor, y: torch.Tensor, masks: torch.Tensor, stream=None) -> None:
-        """One launch: fill x0 [B,6,H,W], y [B,K,3,H,W], masks [B,Km,2,H,W] (fp32, contiguous, on the store's device)."""
+    def _gather_op(self, B: int, idx_ptr: int, flip_ptr: int, x0: torch.Tensor, y: torch.Tensor, masks: torch.Tensor) -> np.ndarray:
         st = self.store
-        B = len(rows)
         for t_, shp in ((x0, (B, 6, st.H, st.W)), (y, (B, self.K, 3, st.H, st.W)), (masks, (B, self.Km, 2, st.H, st.W))):
             if tuple(t_.shape) != shp or t_.dtype != torch.float32 or not t_.is_contiguous() or t_.device != st.frames.device:
                 raise ValueError(f"output buffer must be contiguous fp32 {shp} on {st.frames.device}, got {tuple(t_.shape)} {t_.dtype}")
@@ -128,7 +127,44 @@ class HbmBatchLoader:
         o = ops[0]
         o["op"] = rt.OPC["GATHER_BATCH"]
         o["i"][:7] = [B, st.H, st.W, self.K, self.Km, self.mask_first, st.t_total]
-        o["p"][:6] = [st.frames.data_ptr(), self._idx.data_ptr(), self._flip.data_ptr(), x0.data_ptr(), y.data_ptr(), masks.data_ptr()]
+        o["p"][:6] = [st.frames.data_ptr(), idx_ptr, flip_ptr, x0.data_ptr(), y.data_ptr(), masks.data_ptr()]
+        return ops
+
+    def upload_epoch(self) -> int:
+        """The current epoch's frame indices and flip flags as ONE device table [n_batches][2][B] (one pinned upload per epoch instead
+        of two small copies per step: each such copy is a blit kernel of its own in front of the step's first launch, ~0.1 ms of idle
+        queue per step in the kernel trace).  Returns the number of batches; gather_uploaded(b, ...) then forms batch b."""
+        bs = self.batches()
+        dev = self.store.frames.device
+        host = torch.empty(max(len(bs), 1), 2, self.B, dtype=torch.int32)
+        if dev.type == "cuda":
+            host = host.pin_memory()
+        for b, (rows, flips) in enumerate(bs):
+            host[b, 0] = torch.from_numpy(self.store.frame_index(rows))
+            host[b, 1] = torch.from_numpy(np.ascontiguousarray(flips, dtype=np.int32))
+        if self._table_ev is not None:
+            self._table_ev.synchronize()               # the previous epoch's upload has left its pinned buffer
+        self._table = host.to(dev, non_blocking=True)
+        self._table_host = host                        # keep the pinned source alive until the copy has run
+        if dev.type == "cuda":
+            self._table_ev = torch.cuda.Event()
+            self._table_ev.record()
+        self._table_epoch = self.epoch
+        return len(bs)
+
+    def gather_uploaded(self, b: int, x0: torch.Tensor, y: torch.Tensor, masks: torch.Tensor, stream=None) -> None:
+        """Batch b of the epoch table made by upload_epoch(): one GATHER_BATCH launch, no host -> device copy."""
+        if self._table is None or self._table_epoch != self.epoch:
+            raise RuntimeError("upload_epoch() must be called after set_epoch() and before gather_uploaded()")
+        if stream is not None and self._table_ev is not None:
+            torch.cuda.ExternalStream(stream).wait_event(self._table_ev)       # the table was uploaded on torch's current stream
+        rt.run_ops(self._gather_op(self.B, self._table[b, 0].data_ptr(), self._table[b, 1].data_ptr(), x0, y, masks), stream)
+
+    def gather(self, rows: np.ndarray, flips: np.ndarray, x0: torch.Tensor, y: torch.Tensor, masks: torch.Tensor, stream=None) -> None:
+        """One launch: fill x0 [B,6,H,W], y [B,K,3,H,W], masks [B,Km,2,H,W] (fp32, contiguous, on the store's device)."""
+        st = self.store
+        B = len(rows)
+        ops = self._gather_op(B, self._idx.data_ptr(), self._flip.data_ptr(), x0, y, masks)
         # the index / flag uploads and the kernel go to ONE stream (the reused index buffers would otherwise race)
         ctx = torch.cuda.stream(torch.cuda.ExternalStream(stream)) if stream is not None else contextlib.nullcontext()
         slot = self._slot

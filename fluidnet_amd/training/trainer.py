@@ -237,8 +237,8 @@ class Trainer:
             raise RuntimeError("no plan slot left for the HBM loader's batch shape (raise max_plans)")
         acc: Dict[str, float] = {}
         n = 0
-        for rows, flips in loader.batches():
-            loader.gather(rows, flips, plan.x0.tensor, plan.y.tensor, plan.masks.tensor)
+        for b in range(loader.upload_epoch()):               # one index upload per epoch, one gather launch per batch
+            loader.gather_uploaded(b, plan.x0.tensor, plan.y.tensor, plan.masks.tensor)
             d = self._run_plan(plan)
             n += 1
             for k, v in d.items():

@@ -246,3 +246,56 @@ def test_prep_weights_batch_equals_record_by_record(name):
     rt.run_ops(plan._prep)
     for a, b_ in zip(one, snapshot()):
         assert torch.equal(a.view(torch.uint8), b_.view(torch.uint8))
+
+
+@pytest.mark.parametrize("name", ["medium-bf16", "tiny-transpose-fp32", "large-depth4-bf16"])
+def test_unprep_wgrad_batch_equals_record_by_record(name):
+    """fnet_plan_run folds a run of consecutive UNPREP_WGRAD records of one lane in one launch per 32 records (k_unprep_wgrad_multi):
+    the OIHW gradients must equal, bit for bit, what the records write one at a time (3x3, stride-2 2x2 form, transposed 2x2; > 32
+    records), and a bad record inside a run must stop there and name its index."""
+    import fluidnet_oracle as orc
+    from fluidnet_amd.engine.train_plan import RolloutTrainPlan
+    from fluidnet_amd.models.unet import UNet, UNetConfig
+    from fluidnet_amd.training.physics_loss import PhysicsAwareLoss
+    cfg, prec = {
+        "medium-bf16": (orc.medium_config(dropout=0.0), "bf16"),
+        "large-depth4-bf16": (orc.medium_config(dropout=0.0, base_channels=48, depth=4, downsample="avgpool"), "bf16"),
+        "tiny-transpose-fp32": (tiny_cfg(upsample="transpose"), "fp32"),
+    }[name]
+    m = UNet(UNetConfig(**cfg.__dict__), precision=prec)
+    m.load_state_dict(orc.make_params(cfg, seed=11))
+    m = m.cuda()
+    crit = PhysicsAwareLoss(1.0, 0.01, 0.001, 0.01, 2.0 / 32, True, True, True, "replicate", "forward")
+    plan = RolloutTrainPlan(m.cfg, crit, 1, 32, 32, 1, dtype=prec)
+    plan.bind(torch.device("cuda"), m.flat_params, m.flat_grads)
+    arr = plan._lowered["bwd"]
+    sel = np.nonzero(arr["op"] == rt.OPC["UNPREP_WGRAD"])[0]
+    assert len(sel) >= 8 and np.all(np.diff(sel) == 1), sel          # one run at the end of the backward section
+    run = arr[sel[0]:sel[-1] + 1].copy()
+    run["i"][:, rt.LANE_SLOT] = 0
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for c in plan.pb.convs.values():
+        c["dWk"].tensor.copy_(torch.randn(c["dWk"].tensor.shape, device="cuda", generator=g))
+    grads = m.flat_grads
+    grads.fill_(3.0)
+    for k in range(len(run)):
+        rt.run_ops(run[k:k + 1])
+    torch.cuda.synchronize()
+    one = grads.clone()
+    grads.fill_(5.0)
+    rt.run_ops(run)
+    torch.cuda.synchronize()
+    many = grads.clone()
+    touched = one != 3.0
+    assert int(touched.sum()) > 1000
+    assert torch.equal(one[touched].view(torch.int32), many[touched].view(torch.int32))
+    assert torch.all(many[~touched] == 5.0)                              # nothing outside the weight tensors was written
+    bad = run.copy()
+    bad[3]["i"][0] = 0                                                   # Cout = 0
+    grads.fill_(7.0)
+    with pytest.raises(rt.FluidNetHipError) as ei:
+        rt.run_ops(bad)
+    assert "op #3" in str(ei.value)
+    torch.cuda.synchronize()
+    lo = int(bad[2]["p"][1] - grads.data_ptr()) // 4
+    assert float(grads[lo]) != 7.0                                       # the records before the bad one ran

@@ -124,3 +124,25 @@ def test_gather_matches_reference_fixture_g6(golden_dir, tmp_path, K, preload):
         ld.gather(np.array([2, 2, 2]), np.ones(3, np.int32), x0, y, mk)
         for j, t in enumerate((x0, y, mk)):
             assert np.array_equal(t[0].cpu().numpy(), g[f"flip_on/rollout/{j}"])
+
+
+@pytest.mark.gpu
+def test_epoch_table_gather_equals_per_batch_gather(npz_root):
+    """upload_epoch() + gather_uploaded(b): the whole epoch's indices / flip flags in one upload must form the same batches, bit for bit,
+    as gather(rows, flips) with per-batch uploads; a stale table (another epoch) is refused."""
+    ds = FluidNPZSequenceDataset(npz_root, "train", rollout_steps=3, preload=True, stride=1, is_training=True,
+                                 augmentation_config={"enable_augmentation": True, "flip_probability": 0.5})
+    ld = HbmBatchLoader(HbmSequenceStore(ds), 4, shuffle=True, seed=9)
+    bufs = lambda: (torch.empty(4, 6, 12, 20, device="cuda"), torch.empty(4, 3, 3, 12, 20, device="cuda"), torch.empty(4, 3, 2, 12, 20, device="cuda"))  # noqa: E731
+    for epoch in (0, 3):
+        ld.set_epoch(epoch)
+        bs = ld.batches()
+        assert ld.upload_epoch() == len(bs) > 1 and any(f.sum() for _, f in bs)
+        for b, (rows, flips) in enumerate(bs):
+            a, c = bufs(), bufs()
+            ld.gather(rows, flips, *a)
+            ld.gather_uploaded(b, *c)
+            assert all(torch.equal(p, q) for p, q in zip(a, c))
+    ld.set_epoch(4)
+    with pytest.raises(RuntimeError, match="upload_epoch"):
+        ld.gather_uploaded(0, *bufs())

@@ -1027,48 +1027,91 @@ __device__ __forceinline__ int up_adj(int i, int h, int mode, int Ys[4], float w
     if (i + 1 <= h - 1) { Ys[k] = 2 * i + 2; ws[k++] = 0.25f; }
     return k;
 }
+// Strip form: a block owns UB_S consecutive coarse rows of one image, a thread one coarse column j and 8 channels.  The adjoint is
+// separable, dst[i][j] = sum_a wy_a(i) * hx[2i-1+a], hx[Y] = sum_b wx_b(j) * G[Y][2j-1+b] (a, b = 0..3; a weight is 0 where the fine
+// index does not exist, and the load then hits the zero-weighted ring, which is valid memory), so a thread walks down the fine rows of
+// its strip, forms hx of two new rows per coarse row (2 x 4 loads, issued together) and keeps the two it still needs in registers: every
+// fine row is fetched once per strip (2S + 2 rows per S coarse rows) instead of twice, and 8 loads serve an output instead of 16 (the
+// one-row-per-block form fetched 194 MB for 98 MB of work at 128^2 x 64, PMC).  G = the gradient with its ring copies folded in
+// (fold != 0); ring copies fold only onto the two outermost fine rows / columns, where the taps go through fold_read8.
+constexpr int UB_S = 8;
 template <typename T>
 __global__ __launch_bounds__(256) void k_upsample2x_bwd(const T* g, T* dst, int B, int h, int w, int C, int ldc_g, int coff_g, int ldc_d, int coff_d,
-                                 int fold, int mode, int pm) {
+                                 int fold, int mode, int pm, int S, int strips) {
     const int hp = h + 2, wp = w + 2, groups = C >> 3;
-    const int row = blockIdx.x;  // n*h + i  (interior rows only)
-    const int n = row / h, i = row % h;
+    const int n = blockIdx.x / strips, i0 = (blockIdx.x - n * strips) * S;
+    const int i1 = min(i0 + S, h);                      // coarse rows [i0, i1)
     const int item = blockIdx.y * kThreads + threadIdx.x;
     if (item >= w * groups) return;
     const int j = item / groups, cg = item - j * groups, c0 = cg * 8;
-    int Ys[4], Xs[4];
-    float wy[4], wx[4];
-    const int ny = up_adj(i, h, mode, Ys, wy), nx = up_adj(j, w, mode, Xs, wx);
-    Vec8<T> o;
+    const int H2 = 2 * h, W2 = 2 * w, Wp2 = W2 + 2;
+    // column weights of fine columns 2j-1 .. 2j+2 (bilinear, align_corners=False, edges clamped; nearest: 0 1 1 0)
+    float wx[4];
+    wx[0] = (mode && j >= 1) ? 0.25f : 0.f;
+    wx[1] = (mode && j > 0) ? 0.75f : 1.f;
+    wx[2] = (mode && j < w - 1) ? 0.75f : 1.f;
+    wx[3] = (mode && j + 1 <= w - 1) ? 0.25f : 0.f;
+    const bool do_fold = fold && pm != FNET_PAD_ZEROS;
+    const T* gimg = g + (size_t)n * (H2 + 2) * Wp2 * ldc_g + coff_g + c0;
+    // hx of fine row Y (-1 <= Y <= H2): 4 taps
+    auto row_loads = [&](int Y, Raw8<T> (&r)[4]) {
+        const T* p = gimg + ((size_t)(Y + 1) * Wp2 + 2 * j) * ldc_g;         // padded column of fine column 2j-1 is 2j
 #pragma unroll
-    for (int k = 0; k < 8; ++k) o.v[k] = 0.f;
-    // Ring copies fold only onto the two outermost rows / columns of the fine grid (pad_lo / pad_hi of every padding mode lie there):
-    // away from them -- almost every output -- the taps are plain loads, in the same order and with the same arithmetic as below
-    const int H2 = 2 * h, W2 = 2 * w;
-    const bool inner = !fold || pm == FNET_PAD_ZEROS || (2 * i - 1 >= 2 && 2 * i + 2 <= H2 - 3 && 2 * j - 1 >= 2 && 2 * j + 2 <= W2 - 3);
-    if (inner) {
-        const T* gi = g + (size_t)n * (H2 + 2) * (W2 + 2) * ldc_g + coff_g + c0;
-        for (int a = 0; a < ny; ++a)
-            for (int b = 0; b < nx; ++b) {
-                Vec8<T> v;
-                v.load(gi + ((size_t)(Ys[a] + 1) * (W2 + 2) + Xs[b] + 1) * ldc_g);
-                const float ww = wy[a] * wx[b];
+        for (int b = 0; b < 4; ++b) r[b].load(p + (size_t)b * ldc_g);
+    };
+    // ring copies fold only onto the two outermost fine rows / columns: taps there go through fold_read8 (whole row of taps of an
+    // edge-column thread, every thread on an edge row); everything else is plain loads
+    const bool edge_col = do_fold && (2 * j - 1 < 2 || 2 * j + 2 > W2 - 3);
+    auto row_sum = [&](int Y, const Raw8<T> (&r)[4], float (&hx)[8]) {
+        const bool slow = do_fold && (edge_col || Y < 2 || Y > H2 - 3);
 #pragma unroll
-                for (int k = 0; k < 8; ++k) o.v[k] += ww * (0.f + v.v[k]);
+        for (int k = 0; k < 8; ++k) hx[k] = 0.f;
+        if (!slow) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                float v[8];
+                r[b].unpack(v);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) hx[k] += wx[b] * (0.f + v[k]);
             }
-    } else {
-        for (int a = 0; a < ny; ++a)
-            for (int b = 0; b < nx; ++b) {
+        } else if (Y >= 0 && Y < H2) {
+            for (int b = 0; b < 4; ++b) {
+                const int X = 2 * j - 1 + b;
+                if (X < 0 || X >= W2) continue;
                 float acc[8];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) acc[k] = 0.f;
-                fold_read8<T>(g + coff_g + c0, n, Ys[a], Xs[b], 2 * h, 2 * w, ldc_g, pm, fold, acc);
-                const float ww = wy[a] * wx[b];
+                fold_read8<T>(g + coff_g + c0, n, Y, X, H2, W2, ldc_g, pm, fold, acc);
 #pragma unroll
-                for (int k = 0; k < 8; ++k) o.v[k] += ww * acc[k];
+                for (int k = 0; k < 8; ++k) hx[k] += wx[b] * acc[k];
             }
+        }
+    };
+    float ha[8], hb[8], hc[8], hd[8];                   // hx of fine rows 2i-1, 2i, 2i+1, 2i+2
+    {
+        Raw8<T> ra[4], rb[4];
+        row_loads(2 * i0 - 1, ra);
+        row_loads(2 * i0, rb);
+        __builtin_amdgcn_sched_barrier(0);
+        row_sum(2 * i0 - 1, ra, ha);
+        row_sum(2 * i0, rb, hb);
     }
-    o.store(dst + (((size_t)n * hp + i + 1) * wp + j + 1) * ldc_d + coff_d + c0);
+    for (int i = i0; i < i1; ++i) {
+        Raw8<T> rc[4], rd[4];
+        row_loads(2 * i + 1, rc);
+        row_loads(2 * i + 2, rd);
+        __builtin_amdgcn_sched_barrier(0);              // the eight loads of the two new rows are out before the first unpack
+        row_sum(2 * i + 1, rc, hc);
+        row_sum(2 * i + 2, rd, hd);
+        const float wa = (mode && i >= 1) ? 0.25f : 0.f, wb = (mode && i > 0) ? 0.75f : 1.f;
+        const float wc = (mode && i < h - 1) ? 0.75f : 1.f, wd = (mode && i + 1 <= h - 1) ? 0.25f : 0.f;
+        Vec8<T> o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o.v[k] = (wa * ha[k] + wb * hb[k]) + (wc * hc[k] + wd * hd[k]);
+        o.store(dst + (((size_t)n * hp + i + 1) * wp + j + 1) * ldc_d + coff_d + c0);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { ha[k] = hc[k]; hb[k] = hd[k]; }
+    }
 }
 
 // ------------------------------------------------------------------ POOL2X (nn.AvgPool2d(2) / nn.MaxPool2d(2), unet.py:93-94)
@@ -1646,9 +1689,15 @@ int fnet_op_upsample2x_bwd(const FnetOp& op, hipStream_t st) {
     FNET_CHECK_ARG(B > 0 && h >= 1 && w >= 1 && (op.i[9] == 0 || op.i[9] == 1));
     FNET_CHECK_ARG(vec_ok((void*)op.p[0], op.i[4], op.i[5], C, op.dtype));
     FNET_CHECK_ARG(vec_ok((void*)op.p[1], op.i[6], op.i[7], C, op.dtype));
-    DISPATCH_T(op.dtype, hipLaunchKernelGGL(k_upsample2x_bwd<T>, row_grid(B * h, w * (C / 8)), dim3(kThreads), 0, st,
+    // strips of 8 coarse rows on the large images, 4 below 64 rows (swept on MI355X at B = 64: h = 64 / 32 / 16 take 80 / 42 / 31 us
+    // with 8 / 4 / 4, against 100 / 54 / 29 us for the one-row-per-block form this kernel replaced), fewer where blocks get scarce
+    const int colblocks = (w * (C / 8) + kThreads - 1) / kThreads;
+    int S = h >= 64 ? UB_S : 4;
+    while (S > 1 && (long long)B * ((h + S - 1) / S) * colblocks < 512) S >>= 1;
+    const int strips = (h + S - 1) / S;
+    DISPATCH_T(op.dtype, hipLaunchKernelGGL(k_upsample2x_bwd<T>, row_grid(B * strips, w * (C / 8)), dim3(kThreads), 0, st,
                                             (const T*)op.p[0], (T*)op.p[1], B, h, w, C, op.i[4], op.i[5], op.i[6], op.i[7],
-                                            op.i[8], op.i[9], op.i[10]));
+                                            op.i[8], op.i[9], op.i[10], S, strips));
     FNET_LAUNCH_CHECK();
     return FNET_OK;
 }

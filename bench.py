@@ -212,7 +212,8 @@ def profile_ops(plan_arrays, recs_by_section, dump_path=None):
     # a unit's statistics + normalise / activate records, and its two adjoint passes, are timed TOGETHER (one fnet_plan_run call): the
     # executor issues such a pair as one fused launch on small images, which a record-by-record timing would never see.  The pair's
     # algorithmic bytes are those of its second record (+ a materialised G): what an ideal fusion moves.
-    PAIRS = {("IN_STATS", "APPLY"): "NORM_ACT_FWD", ("INACT_BWD_REDUCE", "INACT_BWD_APPLY"): "NORM_ACT_BWD"}
+    PAIRS = {("IN_STATS", "APPLY"): "NORM_ACT_FWD", ("INACT_BWD_REDUCE", "INACT_BWD_APPLY"): "NORM_ACT_BWD",
+             ("HEAD_FWD", "LOSS_REDUCE"): "HEAD_LOSS_FWD", ("LOSS_GRAD", "HEAD_BWD"): "LOSS_HEAD_BWD"}
     for name, arr in plan_arrays.items():
         recs = recs_by_section[name]
         k = -1
@@ -237,7 +238,12 @@ def profile_ops(plan_arrays, recs_by_section, dump_path=None):
                 a = agg.setdefault(pair, {"ms": 0.0, "n": 0, "flops": 0.0, "bytes": 0.0})
                 a["ms"] += ms
                 a["n"] += 1
-                a["bytes"] += hbm_bytes(rt.OPNAME[r2.code], r2, esz)
+                if pair in ("HEAD_LOSS_FWD", "LOSS_HEAD_BWD"):
+                    # head + loss in one pass: both records' tensors, the prediction (forward) / dpred (backward) not read back
+                    e1 = 2 if r.dtype == rt.BF16 else 4
+                    a["bytes"] += hbm_bytes(kind, r, e1) + hbm_bytes(rt.OPNAME[r2.code], r2, esz) - 3 * 4 * r.i[0] * r.i[1] * r.i[2]
+                else:
+                    a["bytes"] += hbm_bytes(rt.OPNAME[r2.code], r2, esz)
                 if pair == "NORM_ACT_BWD" and len(r.p) > 6 and r.p[6] is not None:
                     a["bytes"] += r.i[0] * r.i[1] * r.i[2] * r.i[3] * esz          # G out
                 k += 1
@@ -292,6 +298,12 @@ def hbm_bytes(kind, r, esz):
         B, H, W = r.i[0], r.i[1], r.i[2]
         planes = 3 + 3 + 1 + 2 + (3 if kind == "LOSS_GRAD" else 0)    # pred, target, density_t, two masks (+ d pred out), fp32 planes
         return B * H * W * 4 * planes
+    if kind == "HEAD_FWD":
+        B, H, W, C = r.i[0], r.i[1], r.i[2], r.i[3]
+        return B * H * W * (C * esz + 2 * 3 * 4)                  # the activation in; z and pred out (fp32 planes)
+    if kind == "HEAD_BWD":
+        B, H, W, C = r.i[0], r.i[1], r.i[2], r.i[3]
+        return B * H * W * (3 * 3 * 4 + 2 * C * esz)              # dpred, z, pred in; the activation in, its gradient out
     if kind == "ADAM":
         n = r.i[0] + (r.i[1] << 31)
         return n * 4 * 7                                          # p, g, m, v in; p, m, v out

@@ -246,7 +246,7 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 extern int g_fnet_last_hip_error;
 // tuning knobs that tests change inside one process: read from the environment ONCE (first use), then only through fnet_set_knob
 // (fnet_plan.hip; include/fluidnet_hip.h) -- no getenv on the launch path
-enum { FNET_KNOB_SA_MINITEMS = 0, FNET_KNOB_SA_CS, FNET_KNOB_SB_MAXHW, FNET_KNOB_WG_PX, FNET_KNOB_COUNT };
+enum { FNET_KNOB_SA_MINITEMS = 0, FNET_KNOB_SA_CS, FNET_KNOB_SB_MAXHW, FNET_KNOB_WG_PX, FNET_KNOB_FUSE_HEAD, FNET_KNOB_COUNT };
 int fnet_knob(int id);
 #define FNET_CHECK_ARG(cond)                     \
     do {                                         \
@@ -314,6 +314,10 @@ bool fnet_can_fuse_stats_apply(const FnetOp& stats_op, const FnetOp& apply_op); 
 int fnet_op_stats_apply(const FnetOp& stats_op, const FnetOp& apply_op, hipStream_t st);
 bool fnet_can_fuse_inact_bwd(const FnetOp& reduce_op, const FnetOp& apply_op);                             // INACT_BWD_REDUCE + INACT_BWD_APPLY, single source, small image
 int fnet_op_inact_bwd_fused(const FnetOp& reduce_op, const FnetOp& apply_op, hipStream_t st);
+bool fnet_can_fuse_head_loss_fwd(const FnetOp& head_op, const FnetOp& loss_op);                            // HEAD_FWD + the LOSS_REDUCE of its prediction
+int fnet_op_head_loss_fwd(const FnetOp& head_op, const FnetOp& loss_op, hipStream_t st);
+bool fnet_can_fuse_loss_head_bwd(const FnetOp& loss_grad_op, const FnetOp& head_bwd_op);                   // LOSS_GRAD + the HEAD_BWD that consumes its dpred
+int fnet_op_loss_head_bwd(const FnetOp& loss_grad_op, const FnetOp& head_bwd_op, hipStream_t st);
 int fnet_op_prep_weights_batch(const FnetOp* ops, int n, hipStream_t st, int* n_done);   // consecutive PREP_WEIGHTS records, one launch per 32
 int fnet_op_unprep_wgrad_batch(const FnetOp* ops, int n, hipStream_t st, int* n_done);  // consecutive UNPREP_WGRAD records, one launch per 32
 FNET_DECL_OP(fnet_op_grad_norm);

@@ -2,6 +2,8 @@
 // its output activation (ml/models/unet.py:294-303), and the finite-difference stencils as free functions.
 // All field planes are fp32 NCHW exactly like the reference's tensors; reductions are wavefront-64 shuffles,
 // one double atomic per block.
+#include <stdlib.h>
+
 #include "fnet_common.h"
 
 namespace {
@@ -146,45 +148,58 @@ __device__ __forceinline__ float adj1d(int j, int n, int pm, int stencil, F S) {
 }
 
 // dpred[n,c,y,x] = gscale*wk*dL_k/dpred + (gradient arriving from the next rollout step's input)
-__global__ __launch_bounds__(256) void k_loss_grad(LossArgs a, const double* sums, const double* gcnt, const float* dnext, int dnext_bstride,
-                            const float* gscale_ptr, float* dpred, int world, float w_mse, float w_div, float w_grad,
-                            float w_emit, float wk) {
-    const int HW = a.H * a.W, total = a.B * HW;
-    const int idx = blockIdx.x * kThreads + threadIdx.x;
-    if (idx >= total) return;
-    const int n = idx / HW, r = idx - n * HW, y = r / a.W, x = r - y * a.W;
+struct LossGradArgs {
+    const double* sums;
+    const double* gcnt;
+    const float* dnext;
+    int dnext_bstride;
+    const float* gscale_ptr;
+    int world;
+    float w_mse, w_div, w_grad, w_emit, wk;
+};
+// the three gradient values of pixel (n, y, x): shared by k_loss_grad and k_loss_head_bwd
+__device__ __forceinline__ void loss_grad_px(const LossArgs& a, const LossGradArgs& q, int n, int y, int x, float& g0, float& g1, float& g2) {
+    const int HW = a.H * a.W, r = y * a.W + x;
     const float* P = a.pred + (size_t)n * 3 * HW;
     const float* T = a.tgt.p + (size_t)n * a.tgt.bstride;
     float inv_den;
     bool zero;
-    masked_den(sums, gcnt, world, inv_den, zero);
-    const float gs = (gscale_ptr ? *gscale_ptr : 1.f) * wk;
-    const float cm = gs * w_mse * 2.f / ((float)a.B * 3.f * (float)HW);
-    float g0 = cm * (P[r] - T[r]);
-    float g1 = cm * (P[HW + r] - T[HW + r]);
-    float g2 = cm * (P[2 * HW + r] - T[2 * HW + r]);
+    masked_den(q.sums, q.gcnt, q.world, inv_den, zero);
+    const float gs = (q.gscale_ptr ? *q.gscale_ptr : 1.f) * q.wk;
+    const float cm = gs * q.w_mse * 2.f / ((float)a.B * 3.f * (float)HW);
+    g0 = cm * (P[r] - T[r]);
+    g1 = cm * (P[HW + r] - T[HW + r]);
+    g2 = cm * (P[2 * HW + r] - T[2 * HW + r]);
     const float sc = (a.stencil == FNET_STENCIL_FORWARD) ? 1.f / a.dx : 0.5f / a.dx;
     if ((a.flags & 1) && !zero) {
-        const float c = gs * w_div * inv_den * sc;
+        const float c = gs * q.w_div * inv_den * sc;
         g1 += c * adj1d(x, a.W, a.pm, a.stencil, [&](int i) { return s_div(a, P, n, y, i, HW); });
         g2 += c * adj1d(y, a.H, a.pm, a.stencil, [&](int i) { return s_div(a, P, n, i, x, HW); });
     }
     if ((a.flags & 2) && !zero) {
-        const float c = gs * w_grad * inv_den * sc;
+        const float c = gs * q.w_grad * inv_den * sc;
         g0 += c * adj1d(x, a.W, a.pm, a.stencil, [&](int i) { return s_gx(a, P, T, n, y, i); });
         g0 += c * adj1d(y, a.H, a.pm, a.stencil, [&](int i) { return s_gy(a, P, T, n, i, x); });
     }
     if (a.flags & 4) {
         const bool allowed = (a.emit.p[(size_t)n * a.emit.bstride + r] > 0.01f) || (a.in0.p[(size_t)n * a.in0.bstride + r] > 0.01f);
-        if (!allowed) g0 += gs * w_emit / ((float)a.B * (float)HW);
+        if (!allowed) g0 += gs * q.w_emit / ((float)a.B * (float)HW);
     }
-    if (dnext) {
+    if (q.dnext) {
         // next input = cat[pred(3), pred[:,0:1], masks]  (trainer.py:374-379): channels 0 and 3 both hit density
-        const float* D = dnext + (size_t)n * dnext_bstride;
+        const float* D = q.dnext + (size_t)n * q.dnext_bstride;
         g0 += D[r] + D[3 * HW + r];
         g1 += D[HW + r];
         g2 += D[2 * HW + r];
     }
+}
+__global__ __launch_bounds__(256) void k_loss_grad(LossArgs a, LossGradArgs q, float* dpred) {
+    const int HW = a.H * a.W, total = a.B * HW;
+    const int idx = blockIdx.x * kThreads + threadIdx.x;
+    if (idx >= total) return;
+    const int n = idx / HW, r = idx - n * HW, y = r / a.W, x = r - y * a.W;
+    float g0, g1, g2;
+    loss_grad_px(a, q, n, y, x, g0, g1, g2);
     float* O = dpred + (size_t)n * 3 * HW;
     O[r] = g0; O[HW + r] = g1; O[2 * HW + r] = g2;
 }
@@ -417,6 +432,207 @@ __global__ __launch_bounds__(256) void k_head_bwd_cg(const float* dpred, const f
     }
 }
 
+// ------------------------------------------------------------------ head + clamp + loss in one pass
+// HEAD_FWD immediately followed by the LOSS_REDUCE that reads its prediction, as ONE launch: a block owns R rows of one image, computes
+// the 1x1 head conv + output activation for those rows and the two halo rows the stencils reach (through the loss's padding map: a
+// replicated / reflected / wrapped row is the head of its source row, a zero-padded one is zero), keeps the three prediction planes
+// of the R + 2 rows in LDS, writes z / pred of its own rows and accumulates the loss sums from LDS: the prediction planes are not
+// read back from memory and two launches become one.  Per pixel the arithmetic is that of k_head_fwd and k_loss_reduce (same order),
+// so z and pred are bit-identical and the fp64 sums differ only in summation order.  Replaces ml/models/unet.py:294-303 +
+// ml/training/physics_loss.py:210-267 for the training plan's (prediction, loss) pair.
+template <typename T>
+__global__ __launch_bounds__(256) void k_head_loss_fwd(const T* __restrict__ src, const float* __restrict__ Wh, const float* __restrict__ bh,
+                                                       float* __restrict__ z, float* __restrict__ pred, LossArgs a, double* sums, int C, int ldc,
+                                                       int coff, int outact, int R) {
+    extern __shared__ float sm[];          // [3][(R + 2) * W] prediction tile, [3 * C + 3] weights and bias
+    __shared__ double red[4 * 6];
+    const int W = a.W, H = a.H, HW = H * W;
+    const int nrb = (H + R - 1) / R;
+    const int n = blockIdx.x / nrb, y0 = (blockIdx.x - n * nrb) * R;
+    const int rows = min(R, H - y0);
+    const int TW = (R + 2) * W;
+    float* tp = sm;
+    float* sw = sm + 3 * TW;
+    for (int i = threadIdx.x; i < 3 * C + 3; i += kThreads) sw[i] = i < 3 * C ? Wh[i] : bh[i - 3 * C];
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < (rows + 2) * W; idx += kThreads) {
+        const int lr = idx / W, x = idx - lr * W;
+        const int y = y0 - 1 + lr;                        // -1 .. H
+        const int sy = pad_src(y, H, a.pm);
+        float pv[3] = {0.f, 0.f, 0.f};
+        if (sy >= 0) {
+            const T* sp = src + (((size_t)n * (H + 2) + sy + 1) * (W + 2) + x + 1) * ldc + coff;
+            float acc[3] = {sw[3 * C], sw[3 * C + 1], sw[3 * C + 2]};
+            for (int c0 = 0; c0 < C; c0 += 8) {
+                Vec8<T> v;
+                v.load(sp + c0);
+#pragma unroll
+                for (int o = 0; o < 3; ++o) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) acc[o] += v.v[k] * sw[o * C + c0 + k];
+                }
+            }
+#pragma unroll
+            for (int o = 0; o < 3; ++o) {
+                const float zz = acc[o];
+                if (outact == FNET_OUT_SIGMOID_TANH) pv[o] = (o == 0) ? 1.f / (1.f + __expf(-zz)) : tanhf(zz);
+                else pv[o] = (o == 0) ? fminf(fmaxf(zz, 0.f), 1.f) : fminf(fmaxf(zz, -1.f), 1.f);
+                if (lr >= 1 && lr <= rows) {
+                    const size_t oi = ((size_t)n * 3 + o) * HW + (size_t)y * W + x;
+                    z[oi] = zz;
+                    pred[oi] = pv[o];
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < 3; ++o) tp[o * TW + idx] = pv[o];
+    }
+    __syncthreads();
+    // the loss sums of this block's rows: P(c, local row, x) from LDS; local row lr <-> image row y0 - 1 + lr, already padding-mapped
+    auto Px = [&](int c, int lr, int xx) -> float {      // x through the padding map, -1 <= xx <= W
+        const int sx = pad_src(xx, W, a.pm);
+        return sx < 0 ? 0.f : tp[c * TW + lr * W + sx];
+    };
+    auto dxp = [&](int c, int lr, int x) -> float {
+        if (a.stencil == FNET_STENCIL_FORWARD) return (Px(c, lr, x + 1) - tp[c * TW + lr * W + x]) / a.dx;
+        return (Px(c, lr, x + 1) - Px(c, lr, x - 1)) / (2.0f * a.dx);
+    };
+    auto dyp = [&](int c, int lr, int x) -> float {
+        if (a.stencil == FNET_STENCIL_FORWARD) return (tp[c * TW + (lr + 1) * W + x] - tp[c * TW + lr * W + x]) / a.dx;
+        return (tp[c * TW + (lr + 1) * W + x] - tp[c * TW + (lr - 1) * W + x]) / (2.0f * a.dx);
+    };
+    double s[6] = {0, 0, 0, 0, 0, 0};
+    const float* Tg = a.tgt.p + (size_t)n * a.tgt.bstride;
+    for (int idx = threadIdx.x; idx < rows * W; idx += kThreads) {
+        const int ly = idx / W, x = idx - ly * W, y = y0 + ly, lr = ly + 1, r = y * W + x;
+        float e = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { const float d = tp[c * TW + lr * W + x] - Tg[c * HW + r]; e += d * d; }
+        s[0] += e;
+        const float fl = fluid_at(a, n, y, x);
+        s[5] += fl;
+        if (a.flags & 1) s[1] += fabsf(dxp(1, lr, x) + dyp(2, lr, x)) * fl;
+        if (a.flags & 2) {
+            const float gx = dxp(0, lr, x) - ddx(Tg, y, x, H, W, a.pm, a.stencil, a.dx);
+            const float gy = dyp(0, lr, x) - ddy(Tg, y, x, H, W, a.pm, a.stencil, a.dx);
+            s[2] += fabsf(gx) * fl;
+            s[3] += fabsf(gy) * fl;
+        }
+        if (a.flags & 4) {
+            const bool allowed = (a.emit.p[(size_t)n * a.emit.bstride + r] > 0.01f) || (a.in0.p[(size_t)n * a.in0.bstride + r] > 0.01f);
+            s[4] += allowed ? 0.f : tp[lr * W + x];
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) s[k] = wave_sum_d(s[k]);
+    if (lane == 0)
+        for (int k = 0; k < 6; ++k) red[wave * 6 + k] = s[k];
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int k = threadIdx.x;
+        atomicAdd(sums + k, red[k] + red[6 + k] + red[12 + k] + red[18 + k]);
+    }
+}
+
+// LOSS_GRAD immediately followed by the HEAD_BWD that consumes its dpred, as ONE launch: a block owns R rows of one image; phase A forms
+// the loss gradient of its pixels (loss_grad_px, as k_loss_grad), writes dpred (kept: the record says it is written) and leaves the gated
+// dz = dpred * clamp' in LDS; phase B is k_head_bwd_cg's channel-group walk over the same pixels with dz from LDS.  dpred, dz and the
+// activation gradient are bit-identical to the separate launches; the head weight / bias gradients differ in fp32 summation order.
+template <typename T, int CG>
+__global__ __launch_bounds__(256) void k_loss_head_bwd(LossArgs a, LossGradArgs q, float* __restrict__ dpred, const float* __restrict__ z,
+                                                       const T* __restrict__ act, const float* __restrict__ Wh, T* __restrict__ dact, float* dWh,
+                                                       float* dbh, int C, int ldc, int coff, int ldc_d, int coff_d, int outact, int R) {
+    extern __shared__ float sm[];          // [3][R * W] dz tile, then [4 waves][3 * C + 3] reduction scratch
+    const int W = a.W, H = a.H, HW = H * W;
+    const int nrb = (H + R - 1) / R;
+    const int n = blockIdx.x / nrb, y0 = (blockIdx.x - n * nrb) * R;
+    const int rows = min(R, H - y0);
+    const int TP = R * W;
+    float* dzt = sm;
+    float* sw = sm + 3 * TP;
+    for (int idx = threadIdx.x; idx < rows * W; idx += kThreads) {
+        const int ly = idx / W, x = idx - ly * W, y = y0 + ly, r = y * W + x;
+        float g[3];
+        loss_grad_px(a, q, n, y, x, g[0], g[1], g[2]);
+#pragma unroll
+        for (int o = 0; o < 3; ++o) {
+            const size_t oi = ((size_t)n * 3 + o) * HW + r;
+            dpred[oi] = g[o];
+            const float zz = z[oi], pv = a.pred[oi];
+            float dz;
+            if (outact == FNET_OUT_SIGMOID_TANH) dz = (o == 0) ? g[o] * pv * (1.f - pv) : g[o] * (1.f - pv * pv);
+            else {
+                const float lo = (o == 0) ? 0.f : -1.f;
+                dz = (zz >= lo && zz <= 1.f) ? g[o] : 0.f;       // torch.clamp backward: inclusive bounds
+            }
+            dzt[o * TP + idx] = dz;
+        }
+    }
+    __syncthreads();
+    const int cg = threadIdx.x & (CG - 1);
+    float w8[3][8], gw[3][8], gb[3];
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+        gb[o] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            gw[o][k] = 0.f;
+            w8[o][k] = (cg * 8 + k < C) ? Wh[o * C + cg * 8 + k] : 0.f;   // zero-padded tail channels: zero gradient
+        }
+    }
+    for (int item = threadIdx.x; item < rows * W * CG; item += kThreads) {
+        const int p = item / CG;
+        const int ly = p / W, x = p - ly * W, y = y0 + ly;
+        float dz[3];
+#pragma unroll
+        for (int o = 0; o < 3; ++o) {
+            dz[o] = dzt[o * TP + p];
+            gb[o] += dz[o];
+        }
+        const size_t pix = ((size_t)n * (H + 2) + y + 1) * (W + 2) + x + 1;
+        Vec8<T> v, d;
+        if (cg * 8 < C) v.load(act + pix * ldc + coff + cg * 8);
+        else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v.v[k] = 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float acc = 0.f;
+#pragma unroll
+            for (int o = 0; o < 3; ++o) {
+                acc += w8[o][k] * dz[o];
+                gw[o][k] += dz[o] * v.v[k];
+            }
+            d.v[k] = acc;
+        }
+        d.store(dact + pix * ldc_d + coff_d + cg * 8);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nred = 3 * C + 3;
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float sv = gw[o][k];
+#pragma unroll
+            for (int off = CG; off < 64; off <<= 1) sv += __shfl_xor(sv, off, 64);
+            if (lane < CG && lane * 8 + k < C) sw[wave * nred + o * C + lane * 8 + k] = sv;
+        }
+        float sv = gb[o];                 // every lane of a pixel counted dz once: keep group 0 only
+#pragma unroll
+        for (int off = CG; off < 64; off <<= 1) sv += __shfl_xor(sv, off, 64);
+        if (lane == 0) sw[wave * nred + 3 * C + o] = sv;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nred; i += kThreads) {
+        const float sv = sw[i] + sw[nred + i] + sw[2 * nred + i] + sw[3 * nred + i];
+        if (i < 3 * C) atomicAdd(dWh + i, sv);
+        else atomicAdd(dbh + (i - 3 * C), sv);
+    }
+}
+
 // ------------------------------------------------------------------ validation metrics (ml/training/metrics.py)
 // One pass over (pred, target, masks) for every sum the reference's metric functions need:
 //   m[0..2] sum (p_c - t_c)^2 per channel   (compute_per_channel_mse, metrics.py:7-12)
@@ -560,14 +776,18 @@ int fnet_op_loss_finalize(const FnetOp& op, hipStream_t st) {
 
 // LOSS_GRAD  i: 0..9 as LOSS_REDUCE,10 world,11 dnext bstride; f: 0 dx,1 w_mse,2 w_div,3 w_grad,4 w_emit,5 wk
 //            p: 0..4 as LOSS_REDUCE,5 sums,6 global count|0,7 dnext [B,>=4,H,W]|0,8 gscale float*|0,9 dpred out [B,3,H,W]
+static bool loss_grad_ok(const FnetOp& op) {
+    return loss_args_ok(op) && op.p[5] && op.p[9] && op.i[10] >= 1 && (op.p[7] == 0 || op.i[11] >= 4 * op.i[1] * op.i[2]);
+}
+static LossGradArgs make_loss_grad_args(const FnetOp& op) {
+    return LossGradArgs{(const double*)op.p[5], (const double*)op.p[6], (const float*)op.p[7], op.i[11], (const float*)op.p[8], op.i[10],
+                        op.f[1], op.f[2], op.f[3], op.f[4], op.f[5]};
+}
 int fnet_op_loss_grad(const FnetOp& op, hipStream_t st) {
-    FNET_CHECK_ARG(loss_args_ok(op) && op.p[5] && op.p[9] && op.i[10] >= 1);
-    FNET_CHECK_ARG(op.p[7] == 0 || op.i[11] >= 4 * op.i[1] * op.i[2]);
+    FNET_CHECK_ARG(loss_grad_ok(op));
     const LossArgs a = make_loss_args(op);
     const int total = a.B * a.H * a.W;
-    hipLaunchKernelGGL(k_loss_grad, dim3((total + kThreads - 1) / kThreads), dim3(kThreads), 0, st, a, (const double*)op.p[5],
-                       (const double*)op.p[6], (const float*)op.p[7], op.i[11], (const float*)op.p[8], (float*)op.p[9], op.i[10],
-                       op.f[1], op.f[2], op.f[3], op.f[4], op.f[5]);
+    hipLaunchKernelGGL(k_loss_grad, dim3((total + kThreads - 1) / kThreads), dim3(kThreads), 0, st, a, make_loss_grad_args(op), (float*)op.p[9]);
     FNET_LAUNCH_CHECK();
     return FNET_OK;
 }
@@ -680,6 +900,80 @@ int fnet_op_head_bwd(const FnetOp& op, hipStream_t st) {
     else if (Cz <= 32) { HEAD_BWD_LAUNCH(32); }
     else { HEAD_BWD_LAUNCH(64); }
 #undef HEAD_BWD_LAUNCH
+    FNET_LAUNCH_CHECK();
+    return FNET_OK;
+}
+
+// ---- executor-level fusion of the head / loss pairs (fnet_plan_run; knob "fuse_head", FNET_FUSE_HEAD=0 disables)
+static int head_rows(int B, int H, int W, int per_row_floats, int min_rows, int max_rows) {
+    // rows per block: ~512-1024 blocks over the launch, the LDS tile within 48 KB
+    int R = (int)(((long long)B * H + 1023) / 1024);
+    if (R < min_rows) R = min_rows;
+    if (R > max_rows) R = max_rows;
+    while (R > 1 && (long long)(R + 2) * W * per_row_floats * 4 > 46 * 1024) --R;
+    if (R > H) R = H;
+    return R;
+}
+bool fnet_can_fuse_head_loss_fwd(const FnetOp& ho, const FnetOp& lo) {
+    if (!fnet_knob(FNET_KNOB_FUSE_HEAD) || ho.i[FNET_LANE_SLOT] != lo.i[FNET_LANE_SLOT]) return false;
+    const int B = ho.i[0], H = ho.i[1], W = ho.i[2], C = ho.i[3];
+    if (B != lo.i[0] || H != lo.i[1] || W != lo.i[2] || ho.i[6] != 3 || !ho.p[4] || ho.p[4] != lo.p[0]) return false;
+    if (C <= 0 || C > 64 || C % 8 != 0 || ho.i[4] % 8 != 0 || ho.i[5] % 8 != 0 || ho.i[5] + C > ho.i[4]) return false;
+    if (!ho.p[0] || !ho.p[1] || !ho.p[2] || !ho.p[3] || (ho.i[7] != 0 && ho.i[7] != 1)) return false;
+    if (!loss_args_ok(lo) || !lo.p[5] || W > 900) return false;
+    return true;
+}
+int fnet_op_head_loss_fwd(const FnetOp& ho, const FnetOp& lo, hipStream_t st) {
+    FNET_CHECK_ARG(fnet_can_fuse_head_loss_fwd(ho, lo));
+    const LossArgs a = make_loss_args(lo);
+    const int C = ho.i[3];
+    const int R = head_rows(a.B, a.H, a.W, 3, 4, 16);
+    const int nrb = (a.H + R - 1) / R;
+    const size_t lds = ((size_t)3 * (R + 2) * a.W + 3 * C + 3) * sizeof(float);
+    FNET_CHECK_ARG(lds <= 64 * 1024);
+    DISPATCH_T(ho.dtype, hipLaunchKernelGGL((k_head_loss_fwd<T>), dim3(a.B * nrb), dim3(kThreads), lds, st, (const T*)ho.p[0],
+                                            (const float*)ho.p[1], (const float*)ho.p[2], (float*)ho.p[3], (float*)ho.p[4], a,
+                                            (double*)lo.p[5], C, ho.i[4], ho.i[5], ho.i[7], R));
+    FNET_LAUNCH_CHECK();
+    return FNET_OK;
+}
+bool fnet_can_fuse_loss_head_bwd(const FnetOp& lg, const FnetOp& hb) {
+    if (!fnet_knob(FNET_KNOB_FUSE_HEAD) || lg.i[FNET_LANE_SLOT] != hb.i[FNET_LANE_SLOT]) return false;
+    const int B = hb.i[0], H = hb.i[1], W = hb.i[2], C = hb.i[3];
+    if (B != lg.i[0] || H != lg.i[1] || W != lg.i[2] || hb.i[8] != 3) return false;
+    if (!loss_grad_ok(lg) || lg.p[9] != hb.p[0] || lg.p[0] != hb.p[2]) return false;
+    for (int k = 0; k < 8; ++k)
+        if (!hb.p[k]) return false;
+    const int Cz = hb.i[10] ? hb.i[10] : (C + 7) / 8 * 8;
+    if (C <= 0 || C > 64 || !(Cz == 8 || Cz == 16 || Cz == 32 || Cz == 64) || Cz < C) return false;
+    if (hb.i[4] % 8 != 0 || hb.i[5] % 8 != 0 || hb.i[6] % 8 != 0 || hb.i[7] % 8 != 0) return false;
+    if (hb.i[5] + (C + 7) / 8 * 8 > hb.i[4] || hb.i[7] + Cz > hb.i[6] || (hb.i[9] != 0 && hb.i[9] != 1) || W > 900) return false;
+    return true;
+}
+int fnet_op_loss_head_bwd(const FnetOp& lg, const FnetOp& hb, hipStream_t st) {
+    FNET_CHECK_ARG(fnet_can_fuse_loss_head_bwd(lg, hb));
+    const LossArgs a = make_loss_args(lg);
+    const LossGradArgs q = make_loss_grad_args(lg);
+    const int C = hb.i[3], Cz = hb.i[10] ? hb.i[10] : (C + 7) / 8 * 8;
+    // ~1024 blocks (swept on MI355X, B = 64 at 128^2: 512 / 1024 / 2048 / 4096 blocks -> 171 / 120 / 138 / 175 us per launch; the
+    // separate LOSS_GRAD + HEAD_BWD launches take 129): phase A wants many blocks, the same-address atomics at the end few
+    int R = (int)(((long long)a.B * a.H + 1023) / 1024);
+    if (R < 1) R = 1;
+    if (R > 16) R = 16;
+    while (R > 1 && (long long)R * a.W * 3 * 4 > 40 * 1024) --R;
+    if (R > a.H) R = a.H;
+    const int nrb = (a.H + R - 1) / R;
+    const size_t lds = ((size_t)3 * R * a.W + 4 * (3 * C + 3)) * sizeof(float);
+    FNET_CHECK_ARG(lds <= 64 * 1024);
+#define LOSS_HEAD_BWD(CGN)                                                                                                              \
+    DISPATCH_T(hb.dtype, hipLaunchKernelGGL((k_loss_head_bwd<T, CGN>), dim3(a.B * nrb), dim3(kThreads), lds, st, a, q, (float*)lg.p[9],   \
+                                            (const float*)hb.p[1], (const T*)hb.p[3], (const float*)hb.p[4], (T*)hb.p[5],               \
+                                            (float*)hb.p[6], (float*)hb.p[7], C, hb.i[4], hb.i[5], hb.i[6], hb.i[7], hb.i[9], R))
+    if (Cz == 8) { LOSS_HEAD_BWD(1); }
+    else if (Cz == 16) { LOSS_HEAD_BWD(2); }
+    else if (Cz == 32) { LOSS_HEAD_BWD(4); }
+    else { LOSS_HEAD_BWD(8); }
+#undef LOSS_HEAD_BWD
     FNET_LAUNCH_CHECK();
     return FNET_OK;
 }

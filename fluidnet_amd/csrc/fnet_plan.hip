@@ -109,6 +109,7 @@ static const struct { const char* name; const char* env; int dflt; } g_knob_def[
     {"sa_cs", "FNET_SA_CS", 0},                // forced channel-slice width of the fused launches (0: widest with a block per CU)
     {"sb_maxhw", "FNET_SB_MAXHW", 32},         // largest image side whose adjoint pair is fused
     {"wg_px", "FNET_WG_PX", 0},                // forced weight-gradient chunk size, 64 | 128 (0: by chunk count)
+    {"fuse_head", "FNET_FUSE_HEAD", 1},        // HEAD_FWD + LOSS_REDUCE and LOSS_GRAD + HEAD_BWD pairs as one launch each
 };
 static int g_knob[FNET_KNOB_COUNT];
 static std::once_flag g_knob_once;
@@ -189,6 +190,14 @@ int fnet_plan_run(const FnetOp* ops, int32_t n_ops, void* stream, int32_t* faile
             } else if (ops[k].op == FNET_OP_INACT_BWD_REDUCE && k + 1 < n_ops && ops[k + 1].op == FNET_OP_INACT_BWD_APPLY &&
                        fnet_can_fuse_inact_bwd(ops[k], ops[k + 1])) {
                 rc = fnet_op_inact_bwd_fused(ops[k], ops[k + 1], st);  // both adjoint passes of a single-source unit in one launch (small images)
+                if (rc == FNET_OK) ++k;
+            } else if (ops[k].op == FNET_OP_HEAD_FWD && k + 1 < n_ops && ops[k + 1].op == FNET_OP_LOSS_REDUCE &&
+                       fnet_can_fuse_head_loss_fwd(ops[k], ops[k + 1])) {
+                rc = fnet_op_head_loss_fwd(ops[k], ops[k + 1], st);    // head + clamp + loss sums in one pass
+                if (rc == FNET_OK) ++k;
+            } else if (ops[k].op == FNET_OP_LOSS_GRAD && k + 1 < n_ops && ops[k + 1].op == FNET_OP_HEAD_BWD &&
+                       fnet_can_fuse_loss_head_bwd(ops[k], ops[k + 1])) {
+                rc = fnet_op_loss_head_bwd(ops[k], ops[k + 1], st);    // loss gradient formed inside the head adjoint
                 if (rc == FNET_OK) ++k;
             } else if (ops[k].op == FNET_OP_PREP_WEIGHTS && k + 1 < n_ops && ops[k + 1].op == FNET_OP_PREP_WEIGHTS && prep_batching) {
                 // a run of weight re-layouts (the start of every training step) goes out as one launch per 32 records

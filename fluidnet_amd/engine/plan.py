@@ -791,12 +791,14 @@ class PlanBuilder:
                 iv += [S.off, C, gw.off if gw is not None else -1, gb.off]
             self.op(ops, "AFFINE_GRAD_MULTI", iv, p=[Ref(self.s_slab), Ref(self.grads)], tag="+".join(g[4] for g in grp))
 
-    def emit_backward(self, ops, t: Tape, dpred: Buf, dx_out: Optional[Buf] = None, dx_channels: int = 6, bucket_cb=None) -> None:
+    def emit_backward(self, ops, t: Tape, dpred: Buf, dx_out: Optional[Buf] = None, dx_channels: int = 6, bucket_cb=None,
+                      pre_head=None) -> None:
         """Adjoint of emit_forward.  Accumulates parameter gradients (dWk scratch for 3x3 weights, grads_flat for the
         rest); writes d(input) [B,dx_channels,H,W] fp32 into dx_out when given.
         bucket_cb(ops, prefixes): called when every layer whose name starts with one of `prefixes` has emitted its last gradient
         op of THIS pass, decoder first (head + ups.*, mid.*, the deepest encoder level); the remaining layers (outer encoder levels,
-        stem) finish with the pass itself.  The data-parallel step starts a bucket's all-reduce there (training/dp.py)."""
+        stem) finish with the pass itself.  The data-parallel step starts a bucket's all-reduce there (training/dp.py).
+        pre_head(ops): emits the producer of dpred immediately before HEAD_BWD."""
         cfg, B, H, W = self.cfg, self.B, self.H, self.W
         zero_at = len(ops)
         self.op(ops, "NOP", [], tag="S_slab")     # placeholder: becomes the ZERO of this pass's S slab once its size is known
@@ -804,6 +806,8 @@ class PlanBuilder:
         s_begin = 0
         x = t.head_in
         G = self.tmp(H, W, x.C)
+        if pre_head is not None:
+            pre_head(ops)                    # the op that writes dpred (LOSS_GRAD), directly in front of its consumer
         self.op(ops, "HEAD_BWD", [B, H, W, self.shapes["head.weight"][1], x.ldc, x.coff, x.C, 0, cfg.out_channels,
                                   rt.OUTACT[cfg.output_activation], x.C],
                 p=[Ref(dpred), Ref(t.z), Ref(t.pred), x.ref, self.pref("head.weight"), Ref(G), self.gref("head.weight"),

@@ -62,16 +62,16 @@ class RolloutTrainPlan:
             else:
                 pr = self.tapes[k - 1].pred
                 st = [(Ref(pr, c * HW), 3 * HW) for c in range(3)] + [(Ref(pr, 0), 3 * HW)]   # prev <- NEW density (trainer.py:378)
-            t = pb.emit_forward(s_fwd, k, st + [em, co])
-            self.tapes.append(t)
             sums = pb.new_buf(f"loss_sums{k}", (8,), "f64")
             terms = pb.new_buf(f"loss_terms{k}", (8,), "f32")
+            pb.emit_zero(s_fwd, sums)          # before the application: HEAD_FWD and LOSS_REDUCE stay adjacent (one fused launch)
+            t = pb.emit_forward(s_fwd, k, st + [em, co])
+            self.tapes.append(t)
             self.sums.append(sums)
             self.terms.append(terms)
             tgt = (Ref(self.y, k * 3 * HW), K * 3 * HW)
             loss_in.append((tgt, st[0], em, co))
             i, flags = pb.loss_ops_args(lc, tgt, st[0], em, co)
-            pb.emit_zero(s_fwd, sums)
             pb.op(s_fwd, "LOSS_REDUCE", i, f=[lc.grid_spacing], p=[Ref(t.pred), tgt[0], st[0][0], em[0], co[0], Ref(sums)], tag=f"loss{k}")
         # ---------------- section 1: loss finalisation (after the optional all-reduce of the fluid counts)
         s_fin: List[OpRec] = []
@@ -112,12 +112,15 @@ class RolloutTrainPlan:
             if w[k] == 0.0 and dnext is None:
                 continue
             tgt, in0, em, co = loss_in[k]
-            pb.emit_loss_grad(s_bwd, lc, self.tapes[k].pred, tgt, in0, em, co, self.sums[k], dnext, None, self.dpred, w[k],
-                              gcnt=Ref(self.gcnt, k) if world > 1 else None, world=world)
+            def loss_grad(ops, k=k, tgt=tgt, in0=in0, em=em, co=co, dnext=dnext):
+                pb.emit_loss_grad(ops, lc, self.tapes[k].pred, tgt, in0, em, co, self.sums[k], dnext, None, self.dpred, w[k],
+                                  gcnt=Ref(self.gcnt, k) if world > 1 else None, world=world)
             pass_down = k > 0 and not gradient_truncation
             dx = pb.new_buf(f"dxin{k}", (B, 4, H, W), "f32") if pass_down else None
             last = k == (passes[-1] if passes else 0)
-            pb.emit_backward(s_bwd, self.tapes[k], self.dpred, dx, 4, bucket_cb=bucket_ready if (last and world > 1) else None)
+            # (the loss gradient is emitted right in front of HEAD_BWD: the executor runs the pair as one launch)
+            pb.emit_backward(s_bwd, self.tapes[k], self.dpred, dx, 4, bucket_cb=bucket_ready if (last and world > 1) else None,
+                             pre_head=loss_grad)
             dnext = (Ref(dx), 4 * HW) if pass_down else None
         pb.emit_unprep(s_bwd, skip=unprepped)
         # the rest of the flat buffer (outer encoder levels, stem; everything when there are no earlier buckets) completes here

@@ -150,8 +150,11 @@ int fnet_device_info(int32_t out[4]);
  * per 32), IN_STATS immediately followed by the APPLY of the same InstanceNorm unit on an image of at most 64 x 64, and
  * INACT_BWD_REDUCE immediately followed by the INACT_BWD_APPLY of the same single-source unit on at most 32 x 32 (ml/models/unet.py:65-69
  * and its autograd adjoint in one kernel each; statistics summed in a fixed order, outputs within one bf16 ulp of the separate
- * launches).  Records that do not qualify, or that would fail their own checks, take the ordinary launchers; results and error
- * reporting are otherwise those of record-by-record execution.
+ * launches); HEAD_FWD immediately followed by the LOSS_REDUCE of its prediction, and LOSS_GRAD immediately followed by the HEAD_BWD that
+ * consumes its dpred (ml/models/unet.py:294-303 + ml/training/physics_loss.py:210-278 in one pass each: z, pred, dpred and the activation
+ * gradient bit-identical to the separate launches, the fp64 loss sums and the head weight / bias gradients to summation order); a run of
+ * UNPREP_WGRAD records of one lane (one launch per 32).  Records that do not qualify, or that would fail their own checks, take the ordinary
+ * launchers; results and error reporting are otherwise those of record-by-record execution.
  */
 int fnet_plan_run(const FnetOp* ops, int32_t n_ops, void* stream, int32_t* failed_index);
 /* The hipStream_t behind side lane `lane` (1 .. FNET_MAX_LANES-1) of the current device, created on first use and owned by the
@@ -159,8 +162,8 @@ int fnet_plan_run(const FnetOp* ops, int32_t n_ops, void* stream, int32_t* faile
  * bucket's RCCL all-reduce behind the lane that produced the bucket's last piece (fluidnet_amd/training/dp.py). */
 int fnet_lane_stream(int32_t lane, void** stream_out);
 /* Development / test control with no reference counterpart: overrides one of the launch heuristics that the library otherwise reads
- * from the environment once per process ("sa_minitems", "sa_cs", "sb_maxhw", "wg_px" = FNET_SA_MINITEMS, FNET_SA_CS, FNET_SB_MAXHW,
- * FNET_WG_PX; INTEGRATION.md "Development knobs").  value < 0 restores the environment's value or the default.  FNET_E_BADARG for an
+ * from the environment once per process ("sa_minitems", "sa_cs", "sb_maxhw", "wg_px", "fuse_head" = FNET_SA_MINITEMS, FNET_SA_CS,
+ * FNET_SB_MAXHW, FNET_WG_PX, FNET_FUSE_HEAD; INTEGRATION.md "Development knobs").  value < 0 restores the environment's value or the default.  FNET_E_BADARG for an
  * unknown name.  Results never depend on a knob beyond summation order; production code does not call this. */
 int fnet_set_knob(const char* name, int32_t value);
 

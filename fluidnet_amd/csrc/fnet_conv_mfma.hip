@@ -716,12 +716,30 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
     atomicAdd(dWk + ((size_t)t * Cout + co) * Cin_w + ci, ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7)));
 }
 
+// per kernel instantiation and device: the largest dynamic-LDS size already granted (the attribute call costs microseconds of host time and
+// a step has ~360 convolution / weight-gradient launches)
 template <typename K>
 int set_lds_limit(K kernel, size_t bytes) {
     if (bytes <= 48 * 1024) return FNET_OK;
+    static size_t granted[16] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+    if (bytes <= granted[dev]) return FNET_OK;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) { g_fnet_last_hip_error = (int)e; return FNET_E_HIP; }
+    granted[dev] = bytes;
     return FNET_OK;
+}
+// compute units of the current device, asked once per device (hipGetDeviceProperties fills a multi-KB struct on every call)
+inline int device_cus() {
+    static int cached[16] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 256;
+    if (cached[dev] == 0) {
+        hipDeviceProp_t prop;
+        cached[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }
+    return cached[dev];
 }
 
 }  // namespace
@@ -751,13 +769,7 @@ int fnet_conv3x3_mfma(const FnetOp& op, hipStream_t st) {
         FNET_CHECK_ARG(op.i[4] + Cin <= op.i[3] && op.i[7] + Cout <= op.i[6]);
     }
     float* stamps = FNET_CONV_STAMPS ? (float*)op.p[4] : nullptr;
-    int cus = 256;
-    {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-            cus = prop.multiProcessorCount;
-    }
+    const int cus = device_cus();
     const int ntaps = mode ? 4 : 9;
     const int halo = mode ? Wp + 1 : 2 * Wp + 2;   // pixels of the input run beyond the tile
     // Tile shape.  Small: 256 px x {32,64} couts, 4 waves, two blocks per CU.  Big: 512 px x {64,128} couts, 8 waves, one block

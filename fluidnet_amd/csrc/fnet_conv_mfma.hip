@@ -17,6 +17,10 @@
 // split across blocks and reduced with fp32 atomics whose lanes run along ci (128-B segments).
 #include <stdlib.h>
 
+#include <array>
+#include <mutex>
+#include <unordered_map>
+
 #include "fnet_common.h"
 
 namespace {
@@ -721,13 +725,18 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
 template <typename K>
 int set_lds_limit(K kernel, size_t bytes) {
     if (bytes <= 48 * 1024) return FNET_OK;
-    static size_t granted[16] = {};
+    // granted sizes per (kernel, device): every instantiation of a kernel template has the same pointer TYPE, so the key is the pointer
+    static std::mutex mu;
+    static std::unordered_map<const void*, std::array<size_t, 16>> granted;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
-    if (bytes <= granted[dev]) return FNET_OK;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    const void* key = reinterpret_cast<const void*>(kernel);
+    std::lock_guard<std::mutex> lock(mu);
+    std::array<size_t, 16>& g = granted[key];          // value-initialised to zeros on first use
+    if (bytes <= g[dev]) return FNET_OK;
+    hipError_t e = hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) { g_fnet_last_hip_error = (int)e; return FNET_E_HIP; }
-    granted[dev] = bytes;
+    g[dev] = bytes;
     return FNET_OK;
 }
 // compute units of the current device, asked once per device (hipGetDeviceProperties fills a multi-KB struct on every call)

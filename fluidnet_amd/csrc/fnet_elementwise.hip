@@ -566,7 +566,11 @@ __device__ __forceinline__ void fold_extras8(const T* gimg, int y, int x, int H,
 
 // Pass 1 of the norm / activation adjoint for one thread's 8 channels: interior pixels q, q + qs, ... < q1 of one image; adds dz to s and
 // dz * xhat to t, writes G where Gbase is given (shared by k_inact_bwd_reduce and k_inact_bwd_fused)
-template <typename T, int ACT>
+// LEAN (the bf16 kernels): the caller passes xa := rstd * gamma, xb := beta - mean * rstd * gamma (u = raw * xa + xb in one FMA), the walk
+// sums g * act'(u) into s and g * act'(u) * raw into t, and the caller restores S1 = drop * s, S2 = drop * rstd * (t - mean * s): 16
+// per-channel constants in registers instead of 40 (110 VGPRs in the single-source form: two waves per SIMD fit beside a weight-gradient
+// wave of the other lane instead of one; capping it at 96 for three spills and is slower)
+template <typename T, int ACT, bool LEAN = false, bool ONE = false>     // ONE: g2img == Gbase == nullptr known at compile time
 __device__ __forceinline__ void inact_reduce_walk(const T* __restrict__ g1img, const T* __restrict__ g2img, const T* __restrict__ rbase, T* __restrict__ Gbase,
                                                   const float (&xa)[8], const float (&xb)[8], const float (&gam)[8], const float (&bet)[8],
                                                   const float (&dsc)[8], float (&s)[8], float (&t)[8], int H, int W, int ldc_g1, int ldc_g2, int ldc_raw,
@@ -621,22 +625,28 @@ __device__ __forceinline__ void inact_reduce_walk(const T* __restrict__ g1img, c
             Vec8<T> go;
 #pragma unroll
             for (int k = 0; k < 8; ++k) go.v[k] = acc[k];
-            if (Gbase) go.store_nt(Gbase + pix_off(pix[u], ldc_G));
+            if (!ONE && Gbase) go.store_nt(Gbase + pix_off(pix[u], ldc_G));
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 // use the value as stored (bf16-rounded in bf16 mode) so that pass 2 sees the same G
-                const float xh = fmaf(r[u].v[k], xa[k], xb[k]);
-                const float uu = fmaf(xh, gam[k], bet[k]);
                 float gq = go.v[k];
                 if (sizeof(T) == 2 && G2) gq = bf2f(f2bf(gq));   // (one source: a stored value, or rounded where it was folded)
-                const float dz = gq * dsc[k] * act_bwd_t<ACT>(uu);
-                s[k] += dz;
-                t[k] = fmaf(dz, xh, t[k]);
+                if (LEAN) {
+                    const float dz = gq * act_bwd_t<ACT>(fmaf(r[u].v[k], xa[k], xb[k]));
+                    s[k] += dz;
+                    t[k] = fmaf(dz, r[u].v[k], t[k]);
+                } else {
+                    const float xh = fmaf(r[u].v[k], xa[k], xb[k]);
+                    const float uu = fmaf(xh, gam[k], bet[k]);
+                    const float dz = gq * dsc[k] * act_bwd_t<ACT>(uu);
+                    s[k] += dz;
+                    t[k] = fmaf(dz, xh, t[k]);
+                }
             }
         }
     };
     constexpr int U = FNET_EW_UR;   // pixels per trip: the gradient and activation loads of all of them are issued first
-    if (g2img) {
+    if (!ONE && g2img) {
         for (; q + (U - 1) * qs < q1; q += U * qs) trip(IntC<U>{}, IntC<1>{});
         for (; q < q1; q += qs) trip(IntC<1>{}, IntC<1>{});
     } else {
@@ -648,7 +658,10 @@ __device__ __forceinline__ void inact_reduce_walk(const T* __restrict__ g1img, c
 // ------------------------------------------------------------------ INACT_BWD_REDUCE (pass 1)
 // G = fold(g1) + fold(g2); dz = G*drop*act'(u); S1 = sum dz, S2 = sum dz*xhat per (n,c).  Writes G (interior) and adds the
 // block's partial sums into S (zeroed by the plan before this op).
-template <typename T, int ACT>
+#ifndef FNET_P1_LEAN
+#define FNET_P1_LEAN 1
+#endif
+template <typename T, int ACT, bool ONE = false>
 __global__ __launch_bounds__(256) void k_inact_bwd_reduce(const T* __restrict__ g1, const T* __restrict__ g2, const T* __restrict__ raw, const float2* __restrict__ stats, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, T* __restrict__ G, float* __restrict__ S, float* dgamma, float* dbeta, int H, int W, int C, int ldc_g1,
                                    int coff_g1, int ldc_g2, int coff_g2, int ldc_raw, int coff_raw, int ldc_G, int coff_G,
@@ -662,6 +675,7 @@ __global__ __launch_bounds__(256) void k_inact_bwd_reduce(const T* __restrict__ 
 #pragma unroll
     for (int k = 0; k < 8; ++k) { s[k] = 0.f; t[k] = 0.f; }
     if (m.active) {
+        constexpr bool LEAN = sizeof(T) == 2 && FNET_P1_LEAN;
         float xa[8], xb[8], gam[8], bet[8], dsc[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -675,7 +689,22 @@ __global__ __launch_bounds__(256) void k_inact_bwd_reduce(const T* __restrict__ 
         T* Gbase = G ? G + img * ldc_G + coff_G + c0 : nullptr;    // G == 0: single-source unit, pass 2 re-reads (and re-folds) g1
         const T* g1img = g1 + img * ldc_g1 + coff_g1 + c0;
         const T* g2img = g2 ? g2 + img * ldc_g2 + coff_g2 + c0 : nullptr;
-        inact_reduce_walk<T, ACT>(g1img, g2img, rbase, Gbase, xa, xb, gam, bet, dsc, s, t, H, W, ldc_g1, ldc_g2, ldc_raw, ldc_G, fold1, fold2, pm, q, qs, q1);
+        if (LEAN) {
+            float ua[8], ub[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { ua[k] = xa[k] * gam[k]; ub[k] = fmaf(xb[k], gam[k], bet[k]); }
+            inact_reduce_walk<T, ACT, true, ONE>(g1img, g2img, rbase, Gbase, ua, ub, ua, ub, ua, s, t, H, W, ldc_g1, ldc_g2, ldc_raw, ldc_G, fold1, fold2, pm, q, qs, q1);
+            // the constants are fetched again here rather than kept live across the walk
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float2 ms = stats[(size_t)n * C + c0 + k];
+                const float d = drop_scale(seed, site, n, c0 + k, drop_p);
+                t[k] = d * ms.y * fmaf(-ms.x, s[k], t[k]);
+                s[k] *= d;
+            }
+        } else {
+            inact_reduce_walk<T, ACT, false, ONE>(g1img, g2img, rbase, Gbase, xa, xb, gam, bet, dsc, s, t, H, W, ldc_g1, ldc_g2, ldc_raw, ldc_G, fold1, fold2, pm, q, qs, q1);
+        }
     }
 #pragma unroll
     for (int k = 0; k < 8; ++k) { red[threadIdx.x * 16 + k] = s[k]; red[threadIdx.x * 16 + 8 + k] = t[k]; }
@@ -1505,12 +1534,16 @@ int fnet_op_inact_bwd_reduce(const FnetOp& op, hipStream_t st) {
     FNET_CHECK_ARG(off_ok(H, W, op.i[4], op.p[1] ? op.i[6] : 8, op.i[8], op.p[6] ? op.i[10] : 8));
     int chunks;
     const int per = cg_pixels_per_block(H * W, B, C, &chunks, 768);
-    DISPATCH_ACT(op.i[14], DISPATCH_T(op.dtype,
-               hipLaunchKernelGGL((k_inact_bwd_reduce<T, ACT>), dim3(chunks, B), dim3(kThreads), 0, st, (const T*)op.p[0],
-                                  (const T*)op.p[1], (const T*)op.p[2], (const float2*)op.p[3], (const float*)op.p[4],
-                                  (const float*)op.p[5], (T*)op.p[6], (float*)op.p[7], (float*)op.p[8], (float*)op.p[9], H, W, C, op.i[4], op.i[5],
-                                  op.i[6], op.i[7], op.i[8], op.i[9], op.i[10], op.i[11], op.i[12], op.i[13], op.i[14],
-                                  op.i[15], (uint32_t)op.i[16], (uint32_t)op.i[17], op.f[0], per)));
+#define FNET_P1_LAUNCH(ONE_)                                                                                                                   \
+    DISPATCH_ACT(op.i[14], DISPATCH_T(op.dtype,                                                                                              \
+               hipLaunchKernelGGL((k_inact_bwd_reduce<T, ACT, ONE_>), dim3(chunks, B), dim3(kThreads), 0, st, (const T*)op.p[0],              \
+                                  (const T*)op.p[1], (const T*)op.p[2], (const float2*)op.p[3], (const float*)op.p[4],                       \
+                                  (const float*)op.p[5], (T*)op.p[6], (float*)op.p[7], (float*)op.p[8], (float*)op.p[9], H, W, C, op.i[4], op.i[5], \
+                                  op.i[6], op.i[7], op.i[8], op.i[9], op.i[10], op.i[11], op.i[12], op.i[13], op.i[14],                      \
+                                  op.i[15], (uint32_t)op.i[16], (uint32_t)op.i[17], op.f[0], per)))
+    // the single-source form without a materialised G (most units of a UNet) is its own instantiation: fewer registers
+    if (op.p[1] == 0 && op.p[6] == 0) { FNET_P1_LAUNCH(true); } else { FNET_P1_LAUNCH(false); }
+#undef FNET_P1_LAUNCH
     FNET_LAUNCH_CHECK();
     return FNET_OK;
 }

@@ -12,9 +12,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 ABL = tuple(int(x) for x in os.environ.get('ABL', '1,2,3').split(','))
-LAYERS = [  # (H, Cin, Cout)
-    (128, 64, 64), (128, 32, 64), (128, 128, 32), (128, 32, 32), (64, 128, 128), (64, 256, 64), (32, 256, 256), (32, 512, 128),
-    (16, 256, 256),
+LAYERS = [  # (H, Cin, Cout): the stride-1 classes of a UNet_medium K4 B64 128^2 step
+    (128, 64, 64), (128, 32, 32), (128, 128, 32), (128, 32, 128), (128, 32, 64), (64, 128, 128), (64, 64, 64), (64, 256, 64), (64, 64, 256),
+    (32, 256, 256), (32, 128, 128), (32, 512, 128), (32, 128, 512), (16, 256, 256),
 ]
 
 

@@ -347,6 +347,30 @@ def reference_gemm():
     return res
 
 
+def reference_stream():
+    """For reading `hbm_roofline.frac`: what plain streaming reaches on THIS box in the same run -- a device-to-device copy of 1 GiB
+    (read + write) and a fill of the same buffer through torch (the runtime's blit / vendor kernels).  Informational:
+    `peak` stays the 8 TB/s data-sheet figure."""
+    import torch
+    n = 1 << 28                                    # int32 elements = 1 GiB
+    a_ = torch.ones(n, device="cuda", dtype=torch.int32)
+    b_ = torch.empty_like(a_)
+    res = {}
+    for key, fn, nbytes in (("copy", lambda: b_.copy_(a_), 8.0 * n), ("fill", lambda: b_.zero_(), 4.0 * n)):
+        for _ in range(2):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        res[key + "_gb_per_s"] = round(nbytes / (e0.elapsed_time(e1) / 5 * 1e-3) / 1e9, 1)
+    del a_, b_
+    res["kind"] = "torch copy_ / zero_ over 1 GiB, measured in this run"
+    return res
+
+
 def pmc_traffic(kernel):
     """Per-launch HBM bytes of `kernel` from the newest committed PMC summary (tools/pmc_traffic.py; rocprofv3 cannot run inside
     the timed process, so the counters come from a separate pass of the same workload), or None."""
@@ -518,6 +542,8 @@ def measure_train(a, arch, depth, B, R, K, steps, warm, world, rank, loader=True
             out["roofline"]["reference_gemm"] = reference_gemm()
         hb = hbm_roofline(agg)
         if hb:
+            if headline:
+                hb["reference_stream"] = reference_stream()
             out["hbm_roofline"] = hb
         out["breakdown_ms_per_step"] = {k: round(v["ms"], 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
         out["breakdown_ms_per_step"]["_sum"] = round(tot, 3)

@@ -246,7 +246,7 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 extern int g_fnet_last_hip_error;
 // tuning knobs that tests change inside one process: read from the environment ONCE (first use), then only through fnet_set_knob
 // (fnet_plan.hip; include/fluidnet_hip.h) -- no getenv on the launch path
-enum { FNET_KNOB_SA_MINITEMS = 0, FNET_KNOB_SA_CS, FNET_KNOB_SB_MAXHW, FNET_KNOB_WG_PX, FNET_KNOB_FUSE_HEAD, FNET_KNOB_COUNT };
+enum { FNET_KNOB_SA_MINITEMS = 0, FNET_KNOB_SA_CS, FNET_KNOB_SB_MAXHW, FNET_KNOB_WG_PX, FNET_KNOB_FUSE_HEAD, FNET_KNOB_WG_XCD, FNET_KNOB_COUNT };
 int fnet_knob(int id);
 #define FNET_CHECK_ARG(cond)                     \
     do {                                         \

@@ -546,7 +546,7 @@ template <int NCO, int NCI, bool S2, int WG_PX>
 __global__ __launch_bounds__(256, 2) void k_wgrad_dma(const bf16_t* __restrict__ src, const bf16_t* __restrict__ dout,
                                                       float* __restrict__ slab, int B, int H, int W, int ldc_in, int coff_in,
                                                       int ldc_do, int coff_do, int log2cw, int chunks_per_block, int nchunks,
-                                                      int nparts, int n_ci_tiles, int Cs) {
+                                                      int nparts, int n_ci_tiles, int Cs, int xcd_map) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int KS = 4 / (NCO * NCI);       // waves that share one (co,ci) panel pair and split the k-steps
     constexpr int NSTG = wg_stages(WG_PX);
@@ -606,8 +606,18 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_dma(const bf16_t* __restrict__
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
-    const int c_begin = blockIdx.x * chunks_per_block;
-    const int c_end = min(nchunks, c_begin + chunks_per_block);
+    // chunk ids of this block: c0 + i * cs, i < n_mine.  Contiguous ranges, or (xcd_map; gridDim.x a multiple of 8) the blocks of one XCD
+    // -- blockIdx.x % 8 -- interleave over one eighth of the chunks, the same eighth of the batch that XCD's tiles of the data-gradient
+    // convolution running beside this launch cover, and walk it front to back as that convolution does
+    int c0 = blockIdx.x * chunks_per_block, cs = 1, n_mine = min(nchunks, c0 + chunks_per_block) - c0;
+    if (xcd_map) {
+        const int X = blockIdx.x & 7, j = blockIdx.x >> 3, SX = gridDim.x >> 3, R = (nchunks + 7) >> 3;
+        const int lo = X * R, hi = min(nchunks, lo + R);
+        c0 = lo + j; cs = SX;
+        n_mine = c0 < hi ? (hi - c0 + SX - 1) / SX : 0;
+    }
+    if (n_mine < 0) n_mine = 0;
+    const int c_begin = 0, c_end = n_mine;
     // NSTG stage buffers, the DMA runs NSTG - 1 chunks ahead: with one block per CU a single stage in flight (27 KB per CU, 7 MB
     // chip-wide) left the kernel latency-bound (solo: 512 blocks 19 % faster than 256).  A chunk has landed when this wave's DMA count is
     // down to the pieces of the chunks issued after it (vmcnt counts in order; the loop issues no other vector memory operation) and
@@ -616,7 +626,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_dma(const bf16_t* __restrict__
     const unsigned smem_lds = (unsigned)(size_t)(lds_void_t*)smem;      // LDS byte address of the dynamic array
 #pragma unroll
     for (int k = 0; k < NSTG - 1; ++k)
-        if (c_begin + k < c_end) wg_issue<NCO, NCI, PPW, S2, WG_PX>(smem_lds, src, dout, c_begin + k, k, wave, H, W, ldc_in, ldc_do, log2cw, cpi, ncx, p_off, p_lds, p_cyx);
+        if (c_begin + k < c_end) wg_issue<NCO, NCI, PPW, S2, WG_PX>(smem_lds, src, dout, c0 + (c_begin + k) * cs, k, wave, H, W, ldc_in, ldc_do, log2cw, cpi, ncx, p_off, p_lds, p_cyx);
     int cur = 0;
     for (int c = c_begin; c < c_end; ++c) {
         const int ahead = min(c_end - 1 - c, NSTG - 2);   // chunks issued after chunk c and still allowed in flight
@@ -635,7 +645,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_dma(const bf16_t* __restrict__
 #else
             if (c + NSTG - 1 < c_end)
 #endif
-                wg_issue<NCO, NCI, PPW, S2, WG_PX>(smem_lds, src, dout, c + NSTG - 1, nb, wave, H, W, ldc_in, ldc_do, log2cw, cpi, ncx, p_off, p_lds, p_cyx);
+                wg_issue<NCO, NCI, PPW, S2, WG_PX>(smem_lds, src, dout, c0 + (c + NSTG - 1) * cs, nb, wave, H, W, ldc_in, ldc_do, log2cw, cpi, ncx, p_off, p_lds, p_cyx);
         }
         const unsigned char* pa = smem + cur * STAGE + cop * (WG_PX * PANEL_ROW);
         const unsigned char* pb = smem + cur * STAGE + DB + cip * (SROWS * PANEL_ROW);
@@ -906,6 +916,8 @@ int fnet_wgrad_mfma(const FnetOp& op, hipStream_t st) {
     const bf16_t* dout = (const bf16_t*)op.p[1];
     float* slab = (float*)op.p[3];
     const dim3 grid(splits, co_tiles, ci_tiles);
+    // (PMC: 136 -> 121 MB fetched per launch -- the data gradient's dout tiles are found in the XCD's L2; step 34.24 -> 34.18 ms)
+    const int xcd_map = (fnet_knob(FNET_KNOB_WG_XCD) && splits % 8 == 0 && splits >= 8) ? 1 : 0;
 #define WGD_LAUNCH3(A, B_, S2_, PX_)                                                                                                  \
     {                                                                                                                                \
         size_t lds = wg_stages(PX_) * ((size_t)A * PX_ * PANEL_ROW + (size_t)B_ * wg_srows(PX_, S2_) * PANEL_ROW);                         \
@@ -913,7 +925,7 @@ int fnet_wgrad_mfma(const FnetOp& op, hipStream_t st) {
         int rc = set_lds_limit(k_wgrad_dma<A, B_, S2_, PX_>, lds);                                                                    \
         if (rc) return rc;                                                                                                           \
         hipLaunchKernelGGL((k_wgrad_dma<A, B_, S2_, PX_>), grid, dim3(kThreads), lds, st, src, dout, slab, B, H, W, op.i[3], op.i[4], \
-                           op.i[6], op.i[7], log2cw, cpb, nch, nparts, ci_tiles, Cs);                                                \
+                           op.i[6], op.i[7], log2cw, cpb, nch, nparts, ci_tiles, Cs, xcd_map);                                       \
     }
 #define WGD_LAUNCH2(A, B_, S2_)                                                                                                       \
     {                                                                                                                                \

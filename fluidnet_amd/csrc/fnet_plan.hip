@@ -110,6 +110,7 @@ static const struct { const char* name; const char* env; int dflt; } g_knob_def[
     {"sb_maxhw", "FNET_SB_MAXHW", 32},         // largest image side whose adjoint pair is fused
     {"wg_px", "FNET_WG_PX", 0},                // forced weight-gradient chunk size, 64 | 128 (0: by chunk count)
     {"fuse_head", "FNET_FUSE_HEAD", 1},        // HEAD_FWD + LOSS_REDUCE and LOSS_GRAD + HEAD_BWD pairs as one launch each
+    {"wg_xcd", "FNET_WG_XCD", 1},              // weight-gradient chunks dealt to blocks per XCD (the eighth of the batch the dgrad conv beside it walks)
 };
 static int g_knob[FNET_KNOB_COUNT];
 static std::once_flag g_knob_once;

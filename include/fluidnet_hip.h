@@ -162,8 +162,8 @@ int fnet_plan_run(const FnetOp* ops, int32_t n_ops, void* stream, int32_t* faile
  * bucket's RCCL all-reduce behind the lane that produced the bucket's last piece (fluidnet_amd/training/dp.py). */
 int fnet_lane_stream(int32_t lane, void** stream_out);
 /* Development / test control with no reference counterpart: overrides one of the launch heuristics that the library otherwise reads
- * from the environment once per process ("sa_minitems", "sa_cs", "sb_maxhw", "wg_px", "fuse_head" = FNET_SA_MINITEMS, FNET_SA_CS,
- * FNET_SB_MAXHW, FNET_WG_PX, FNET_FUSE_HEAD; INTEGRATION.md "Development knobs").  value < 0 restores the environment's value or the default.  FNET_E_BADARG for an
+ * from the environment once per process ("sa_minitems", "sa_cs", "sb_maxhw", "wg_px", "fuse_head", "wg_xcd" = FNET_SA_MINITEMS, FNET_SA_CS,
+ * FNET_SB_MAXHW, FNET_WG_PX, FNET_FUSE_HEAD, FNET_WG_XCD; INTEGRATION.md "Development knobs").  value < 0 restores the environment's value or the default.  FNET_E_BADARG for an
  * unknown name.  Results never depend on a knob beyond summation order; production code does not call this. */
 int fnet_set_knob(const char* name, int32_t value);
 

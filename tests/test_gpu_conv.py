@@ -126,6 +126,22 @@ def test_wgrad_chunk_sizes_on_every_shape(px, knobs):
         assert not failures, f"s2 {shape}: " + "\n".join(failures)
 
 
+@pytest.mark.parametrize("xcd", ["0", "1"])
+def test_wgrad_chunk_dealing_contiguous_and_per_xcd(xcd, knobs):
+    """k_wgrad_dma deals its chunks to blocks either as contiguous ranges or interleaved per XCD (knob wg_xcd, default on where the
+    block count along the chunk axis is a multiple of 8): every chunk exactly once either way, ragged last ranges and blocks without a
+    chunk included."""
+    knobs("wg_xcd", xcd)
+    for shape in WG_PIPE_SHAPES + [(64, 16, 16, 64, 64, 64, 0, 64, 0), (3, 48, 40, 128, 64, 128, 0, 64, 0)]:
+        pb, ops = _mk(*shape, "bf16", "mfma")
+        failures = lockstep(pb, ops[1:])
+        assert not failures, f"{shape}: " + "\n".join(failures)
+    for shape in S2_SHAPES[:3]:
+        pb, ops = _mk_s2(*shape)
+        failures = lockstep(pb, ops[2:])
+        assert not failures, f"s2 {shape}: " + "\n".join(failures)
+
+
 def test_wgrad_128_pixel_chunks_selected_at_full_size():
     # 16 images of 128x128, 64 -> 64 channels: 2048 chunks of 128 pixels >= 3 per block, so the launcher takes the 128-pixel form itself
     assert "FNET_WG_PX" not in os.environ

@@ -326,11 +326,13 @@ def hbm_roofline(agg):
 
 def reference_gemm():
     """For reading `roofline.frac`: what the vendor-tuned dense bf16 GEMM (torch.matmul -> hipBLASLt) reaches on THIS box, on a large square
-    problem and on the plain-GEMM shape of the step's heaviest convolution class (M = pixels of 64 images of 130x130, N = 64 couts,
-    K = 9 * 64, no im2col cost counted).  Informational: `peak` stays the data-sheet figure."""
+    problem and on the plain-GEMM shapes of the step's three heaviest convolution classes (M = padded pixels of 64 images, N = couts,
+    K = 9 * cin, no im2col cost counted; k_conv3x3_dma runs those layers at 817 / 935 / 923 TFLOP/s, halo staging and epilogue included:
+    profiles/r3y_op_classes.txt).  Informational: `peak` stays the data-sheet figure."""
     import torch
     res = {}
-    for key, (m, n, k) in (("square_8192", (8192, 8192, 8192)), ("conv_64to64_128x128_shape", (1081600, 64, 576))):
+    for key, (m, n, k) in (("square_8192", (8192, 8192, 8192)), ("conv_64to64_128x128_shape", (1081600, 64, 576)),
+                           ("conv_128to128_64x64_shape", (278784, 128, 1152)), ("conv_256to256_32x32_shape", (73984, 256, 2304))):
         a_ = torch.randn(m, k, device="cuda", dtype=torch.bfloat16)
         b_ = torch.randn(k, n, device="cuda", dtype=torch.bfloat16)
         for _ in range(3):

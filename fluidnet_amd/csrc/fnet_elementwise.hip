@@ -1533,7 +1533,11 @@ int fnet_op_inact_bwd_reduce(const FnetOp& op, hipStream_t st) {
     FNET_CHECK_ARG(op.p[3] && op.p[4] && op.p[5] && op.p[7] && cg_ok(C, B) && ((op.p[8] == 0) == (op.p[9] == 0)));
     FNET_CHECK_ARG(off_ok(H, W, op.i[4], op.p[1] ? op.i[6] : 8, op.i[8], op.p[6] ? op.i[10] : 8));
     int chunks;
-    const int per = cg_pixels_per_block(H * W, B, C, &chunks, 768);
+    // The single-source form (110 VGPRs) gets 6 blocks per CU instead of the family's 3: beside a 232-register weight-gradient wave only two
+    // of its blocks are resident per CU, and 3 per CU then run as a full round and a half-empty one (same-box A/B, K4 B64 128^2: 768 ->
+    // 34.08 ms, 512 -> 33.93, 1536 -> 33.84, 3072 -> 33.86; alone the launch is 2 % slower than with 768)
+    static const int p1one = [] { const char* e = getenv("FNET_P1ONE_BLOCKS"); return e ? atoi(e) : 1536; }();
+    const int per = cg_pixels_per_block(H * W, B, C, &chunks, (op.p[1] == 0 && op.p[6] == 0) ? p1one : 768);
 #define FNET_P1_LAUNCH(ONE_)                                                                                                                   \
     DISPATCH_ACT(op.i[14], DISPATCH_T(op.dtype,                                                                                              \
                hipLaunchKernelGGL((k_inact_bwd_reduce<T, ACT, ONE_>), dim3(chunks, B), dim3(kThreads), 0, st, (const T*)op.p[0],              \

@@ -1537,7 +1537,9 @@ int fnet_op_inact_bwd_reduce(const FnetOp& op, hipStream_t st) {
     // of its blocks are resident per CU, and 3 per CU then run as a full round and a half-empty one (same-box A/B, K4 B64 128^2: 768 ->
     // 34.08 ms, 512 -> 33.93, 1536 -> 33.84, 3072 -> 33.86; alone the launch is 2 % slower than with 768)
     static const int p1one = [] { const char* e = getenv("FNET_P1ONE_BLOCKS"); return e ? atoi(e) : 1536; }();
-    const int per = cg_pixels_per_block(H * W, B, C, &chunks, (op.p[1] == 0 && op.p[6] == 0) ? p1one : 768);
+    // (the general form too: 768 -> 1536 blocks 35.12 -> 34.94 ms; 2304: 34.32 against 34.19; every channel-group kernel at 1536: +0.25 ms)
+    static const int p1two = [] { const char* e = getenv("FNET_P1TWO_BLOCKS"); return e ? atoi(e) : 1536; }();
+    const int per = cg_pixels_per_block(H * W, B, C, &chunks, (op.p[1] == 0 && op.p[6] == 0) ? p1one : p1two);
 #define FNET_P1_LAUNCH(ONE_)                                                                                                                   \
     DISPATCH_ACT(op.i[14], DISPATCH_T(op.dtype,                                                                                              \
                hipLaunchKernelGGL((k_inact_bwd_reduce<T, ACT, ONE_>), dim3(chunks, B), dim3(kThreads), 0, st, (const T*)op.p[0],              \
